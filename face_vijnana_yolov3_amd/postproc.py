@@ -1,0 +1,68 @@
+"""Host side of the detect post-processing: device tensors in, device tensors / BoundBox out.
+
+Mirrors the tail of FaceDetector.detect (reference face_detection.py:900-949) and the BoundBox
+record (reference yolov3_detect.py:126-163)."""
+import numpy as np
+
+from ._lib import lib, ptr
+
+
+class BoundBox(object):
+    """Mutable detection record; same attribute surface as the reference's BoundBox
+    (yolov3_detect.py:126-163): callers mutate xmin..ymax in place (face_detection.py:700-710)."""
+
+    def __init__(self, xmin, ymin, xmax, ymax, objness=None, classes=None, anchor=None, subject_id=-1):
+        self.xmin = xmin
+        self.ymin = ymin
+        self.xmax = xmax
+        self.ymax = ymax
+        self.objness = objness
+        self.classes = classes
+        self.anchor = anchor
+        self.subject_id = subject_id
+        self.label = -1
+        self.score = -1
+
+    def get_label(self):
+        if self.label == -1:
+            self.label = int(np.argmax(self.classes))
+        return self.label
+
+    def get_score(self):
+        if self.score == -1:
+            self.score = self.classes[self.get_label()]
+        return np.min([self.score, 1.0])
+
+    def get_relative_bb(self, width, height):
+        return (int(self.xmin / width * 100.), int(self.ymin / height * 100.),
+                int((self.xmax - self.xmin) / width * 100.), int((self.ymax - self.ymin) / height * 100.))
+
+
+def decode_nms(ctx, head, image_size, conf_th, iou_th, num_cands):
+    """head: (n, G, G, 6) float32 CUDA tensor -> dict of CUDA tensors
+    boxes (n,K,4) i32, cell (n,K) i32, obj (n,K) f32, score (n,K) f32, count (n,) i32."""
+    import torch
+    assert head.is_cuda and head.dtype == torch.float32 and head.dim() == 4 and head.shape[3] == 6
+    head = head.contiguous()
+    n, g = head.shape[0], head.shape[1]
+    k = int(num_cands)
+    dev = head.device
+    boxes = torch.empty((n, k, 4), dtype=torch.int32, device=dev)
+    cell = torch.empty((n, k), dtype=torch.int32, device=dev)
+    obj = torch.empty((n, k), dtype=torch.float32, device=dev)
+    score = torch.empty((n, k), dtype=torch.float32, device=dev)
+    count = torch.empty((n,), dtype=torch.int32, device=dev)
+    rc = lib().fv_decode_nms(ctx.handle, ptr(head), n, g, int(image_size), float(conf_th), float(iou_th), k,
+                             ptr(boxes), ptr(cell), ptr(obj), ptr(score), ptr(count))
+    ctx.check(rc, 'fv_decode_nms')
+    return dict(boxes=boxes, cell=cell, obj=obj, score=score, count=count)
+
+
+def to_boundboxes(res, img=0):
+    """Device result of decode_nms -> list[BoundBox] for one image, reference order (ascending
+    score).  Coordinates are np.int64 and scores np.float32 as in the reference."""
+    c = int(res['count'][img])
+    b = res['boxes'][img, :c].cpu().numpy().astype(np.int64)
+    o = res['obj'][img, :c].cpu().numpy()
+    s = res['score'][img, :c].cpu().numpy()
+    return [BoundBox(b[k, 0], b[k, 1], b[k, 2], b[k, 3], objness=o[k], classes=[s[k]]) for k in range(c)]

@@ -1,0 +1,112 @@
+"""GPU parity of fv_decode_nms (through the C ABI) against the golden vectors minted from the
+reference and against the C oracle on seeded random frames."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from face_vijnana_yolov3_amd._lib import Context
+    return Context(0)
+
+
+def _run(ctx, head, S, cth, ith, nc):
+    import torch
+    from face_vijnana_yolov3_amd.postproc import decode_nms
+    r = decode_nms(ctx, torch.from_numpy(np.ascontiguousarray(head)).cuda(), S, cth, ith, nc)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in r.items()}
+
+
+def test_golden_cases_bit_exact(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'detect_cases.npz'))
+    head, meta, out, cnt, names = g['head'], g['meta'], g['out'], g['out_count'], g['names']
+    for k in range(len(head)):
+        cth, ith, nc, _ = meta[k]
+        r = _run(ctx, head[k:k + 1], 416, cth, ith, int(nc))
+        c = int(r['count'][0])
+        assert c == cnt[k], names[k]
+        np.testing.assert_array_equal(r['boxes'][0, :c], out[k, :c, :4].astype(np.int32), err_msg=str(names[k]))
+        np.testing.assert_array_equal(r['cell'][0, :c], out[k, :c, 4].astype(np.int32), err_msg=str(names[k]))
+        np.testing.assert_allclose(r['obj'][0, :c], out[k, :c, 5], rtol=2.5e-7, atol=0)
+        np.testing.assert_allclose(r['score'][0, :c], out[k, :c, 6], rtol=4e-7, atol=0)
+        assert np.all(r['boxes'][0, c:] == -1) and np.all(r['cell'][0, c:] == -1)
+
+
+def _synth(rng, n, grid):
+    y = np.zeros((n, grid, grid, 6), np.float32)
+    y[..., 0] = rng.normal(0, 2, (n, grid, grid)); y[..., 5] = rng.normal(0, 2, (n, grid, grid))
+    y[..., 1:3] = rng.uniform(0, 1, (n, grid, grid, 2)); y[..., 3:5] = rng.uniform(0, 0.3, (n, grid, grid, 2))
+    return y
+
+
+@pytest.mark.parametrize('grid,S,n', [(13, 416, 2048), (19, 608, 512), (1, 32, 3), (22, 704, 64)])
+def test_random_frames_vs_oracle_bit_exact(ctx, grid, S, n):
+    from oracle import postproc as oracle_pp
+    head = _synth(np.random.default_rng(99 + grid), n, grid)
+    want = oracle_pp.detect_postproc(head, S, 0.5, 0.5, 60)
+    got = _run(ctx, head, S, 0.5, 0.5, 60)
+    np.testing.assert_array_equal(got['count'], want['count'])
+    np.testing.assert_array_equal(got['boxes'], want['boxes'])
+    np.testing.assert_array_equal(got['cell'], want['cell'])
+    # same exp definition on both sides (correctly rounded f32): bit-exact floats
+    np.testing.assert_array_equal(got['score'], want['score'])
+    np.testing.assert_array_equal(got['obj'], want['obj'])
+
+
+def test_ties_break_toward_lower_cell(ctx):
+    """Exact score ties are undefined in the reference; ours (and the oracle's) definition."""
+    from oracle import postproc as oracle_pp
+    head = np.zeros((1, 13, 13, 6), np.float32)
+    head[..., 0] = 3.0; head[..., 5] = 2.0; head[..., 1:3] = 0.5; head[..., 3:5] = 0.3
+    want = oracle_pp.detect_postproc(head, 416, 0.5, 0.5, 60)
+    got = _run(ctx, head, 416, 0.5, 0.5, 60)
+    for k in ('count', 'boxes', 'cell', 'score'):
+        np.testing.assert_array_equal(got[k], want[k])
+
+
+def test_full_size_config4_properties(ctx):
+    """BASELINE config 4: 10k frames.  Size-independent properties + oracle on a 256-frame subset."""
+    from oracle import postproc as oracle_pp
+    head = _synth(np.random.default_rng(99), 10000, 13)
+    got = _run(ctx, head, 416, 0.5, 0.5, 60)
+    c = got['count']
+    assert c.min() >= 0 and c.max() <= 60
+    idx = np.arange(60)[None, :] < c[:, None]
+    d = got['score'][:, 1:] - got['score'][:, :-1]
+    assert np.all(d[idx[:, 1:]] >= 0)                             # ascending
+    assert np.all(got['score'][idx] >= 0.5) and np.all(got['score'][idx] <= 1.0)
+    b = got['boxes']
+    assert np.all(b[idx][:, 0] <= b[idx][:, 2]) and np.all(b[idx][:, 1] <= b[idx][:, 3])
+    assert b[idx].min() >= 0 and b[idx].max() <= 415
+    # survivors are mutually non-suppressing: pairwise IoU < th among kept boxes of a frame
+    for f in range(0, 10000, 500):
+        k = int(c[f]); bb = b[f, :k]
+        ii, jj = np.triu_indices(k, 1)
+        if len(ii):
+            iou = oracle_pp.bbox_iou(bb[ii], bb[jj])
+            assert not np.any(iou >= 0.5)
+    # idempotence: same input twice -> identical output
+    got2 = _run(ctx, head, 416, 0.5, 0.5, 60)
+    for k in got:
+        np.testing.assert_array_equal(got[k], got2[k])
+    sub = slice(0, 256)
+    want = oracle_pp.detect_postproc(head[sub], 416, 0.5, 0.5, 60)
+    for k in ('count', 'boxes', 'cell', 'score', 'obj'):
+        np.testing.assert_array_equal(got[k][sub], want[k])
+
+
+def test_invalid_arguments_report_errors(ctx):
+    import torch
+    from face_vijnana_yolov3_amd._lib import FvError
+    from face_vijnana_yolov3_amd.postproc import decode_nms
+    with pytest.raises(FvError):
+        decode_nms(ctx, torch.zeros((1, 30, 30, 6), device='cuda'), 960, 0.5, 0.5, 60)
+    with pytest.raises(FvError):
+        decode_nms(ctx, torch.zeros((1, 13, 13, 6), device='cuda'), 416, 0.5, 0.5, 0)
+    r = decode_nms(ctx, torch.zeros((0, 13, 13, 6), device='cuda'), 416, 0.5, 0.5, 60)
+    assert r['count'].numel() == 0
