@@ -33,8 +33,50 @@ def lib():
         L.fv_decode_nms.restype = c_int
         L.fv_decode_nms.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        _declare(L)
         _lib = L
     return _lib
+
+
+class LayerDesc(ctypes.Structure):
+    """fv_layer_desc of include/fv_hotpath.h."""
+    _fields_ = [('darknet_index', ctypes.c_int32), ('ksize', ctypes.c_int32), ('stride', ctypes.c_int32),
+                ('cin', ctypes.c_int32), ('cout', ctypes.c_int32), ('has_bn', ctypes.c_int32),
+                ('role', ctypes.c_int32), ('in_div', ctypes.c_int32), ('out_div', ctypes.c_int32),
+                ('w_off', ctypes.c_int64), ('gamma_off', ctypes.c_int64), ('beta_off', ctypes.c_int64),
+                ('mean_off', ctypes.c_int64), ('var_off', ctypes.c_int64)]
+
+
+BUCKET_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64)
+
+
+def _declare(L):
+    i32, i64, f32, f64, vp, sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, c_void_p, ctypes.c_size_t
+    sig = {
+        'fv_num_layers': (i32, []),
+        'fv_layer': (i32, [i32, ctypes.POINTER(LayerDesc)]),
+        'fv_param_count': (i64, []),
+        'fv_state_count': (i64, []),
+        'fv_workspace_bytes': (sz, [i32, i32, i32]),
+        'fv_forward_infer': (i32, [vp, vp, vp, vp, i32, i32, vp, sz, vp]),
+        'fv_train_step': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, vp, BUCKET_FN, vp]),
+        'fv_adam_step': (i32, [vp, vp, vp, vp, vp, i64, i64, f64, f64, f64, f64, f64]),
+        'fv_conv2d_forward': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp]),
+        'fv_conv2d_stat_rows': (i32, [i64]),
+        'fv_conv2d_dgrad': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+        'fv_conv2d_wgrad': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+        'fv_transpose_weights': (i32, [vp, vp, i32, i32, i32, i32, vp]),
+        'fv_pack_first_layer': (i32, [vp, vp, i32, i32, vp]),
+        'fv_bn_finalize': (i32, [vp, vp, vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp]),
+        'fv_bn_act': (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32]),
+        'fv_bn_bwd_scratch_floats': (i64, [i64, i32]),
+        'fv_bn_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp, vp, vp, vp]),
+        'fv_mse_loss_grad': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
 
 
 class Context:

@@ -1,0 +1,61 @@
+// Internal launch interface of the fp32-MFMA implicit-GEMM convolution kernels (conv_mfma.hip,
+// wgrad_mfma.hip).  NHWC activations, OHWI-style weights ([n][tap][c], c contiguous).
+#pragma once
+#include "common.h"
+
+// One "tap" = one (dh, dw) input offset and the slot of its weight slab.
+struct FvTaps {
+    int n;
+    int dh[9];
+    int dw[9];
+    int wslot[9];
+};
+
+enum { FV_EPI_AFFINE = 1, FV_EPI_LEAKY = 2, FV_EPI_ADD = 4, FV_EPI_STATS = 8 };
+
+// Gather-convolution:  out[b, oh*os+oph, ow*os+opw, n] = sum_{t,c} x[b, oh*is+dh[t], ow*is+dw[t], c] * w[n][wslot[t]][c]
+// over the output lattice (B, Hl, Wl); out-of-range input pixels read as zero.  This one form
+// covers forward (stride 1/2, 3x3/1x1), data-gradient (stride 1: mirrored taps; stride 2: four
+// parity classes, one per blockIdx.z) and the small-Cin first layer (gather mode, K = taps*Cin <= 32).
+struct FvConvArgs {
+    const float* x;
+    const float* w;
+    float* out;
+    const float* addend;  // FV_EPI_ADD: same layout as out
+    const float* scale;   // FV_EPI_AFFINE: per-n (may be NULL = 1)
+    const float* shift;   // FV_EPI_AFFINE: per-n (may be NULL = 0)
+    float* psum;          // FV_EPI_STATS: [mtiles][Nout] per-tile column sums of the raw result
+    float* psq;           //                and of its squares
+    int B, Hin, Win, Cin;
+    int Hl, Wl;
+    int Hout, Wout, Nout;
+    int is, os;
+    int Tw;       // taps per output channel in w
+    int M;        // B*Hl*Wl
+    int epi;
+    float leaky;
+    int nclass;   // 1, or 4 for stride-2 data-gradient
+    int oph[4], opw[4];
+    FvTaps taps[4];
+};
+
+// Number of M tiles (rows of psum/psq) the conv launch will use for this problem.
+int fv_conv_mtiles(int M, int Nout);
+int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a);
+
+// Weight gradient:  dw[n][wslot[t]][c] += sum_{b,oh,ow} dy[b,oh,ow,n] * x[b, oh*is+dh[t], ow*is+dw[t], c]
+// (dy is dense over the lattice (B,Hl,Wl) with Ndy channels per pixel of which the first N are used).
+// Accumulates with float atomics: the caller zeroes dw first.
+struct FvWgradArgs {
+    const float* x;
+    const float* dy;
+    float* dw;
+    int B, Hin, Win, Cin;  // x dims
+    int Hl, Wl, N;         // dy lattice and used channels
+    int Ndy;               // channel stride of dy (>= N)
+    int is;
+    int Tw;                // taps per output channel in dw
+    int M;                 // B*Hl*Wl
+    FvTaps taps;
+};
+int fv_wgrad_launch(fv_ctx* ctx, const FvWgradArgs& a);

@@ -1,0 +1,288 @@
+// fp32 implicit-GEMM gather-convolution on CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Serves the Darknet-53 forward convs (reference yolov3_detect.py:196-215 `_conv_block`:
+// ZeroPadding2D(1) + Conv2D 'valid'), the head conv (face_detection.py:348-352) and, with
+// mirrored / parity-class tap lists, every data-gradient.  Exact fp32: the MFMA result is a
+// k-ordered fmaf chain, so the numerics equal a scalar fp32 convolution.
+//
+// GEMM view: M = output pixels of the lattice, N = output channels, K = taps x Cin.
+//  * block = 256 threads (4 waves), tile 128 x BN (BN = 128/64/32), K step 32
+//  * A (pixels x channels) and B (out-channels x channels) tiles are both K-contiguous in HBM
+//    (NHWC activations, OHWI weights): 16-byte loads, register-staged into a double-buffered
+//    LDS image [row][32+4] whose 36-dword row stride makes the ds_read_b128 fragment reads
+//    conflict-free (16 lanes of a group hit 16 distinct 4-bank slots)
+//  * K permutation: within an 8-deep chunk lane-half h supplies k = 4h+j to MFMA j, so one
+//    ds_read_b128 per operand block feeds four MFMAs
+//  * epilogue: optional per-channel affine (+LeakyReLU, +residual add) for inference, or raw
+//    store + deterministic per-tile column sums / sums of squares for training-mode BatchNorm
+//  * XCD-aware bijective remap of blockIdx so tiles that share an A panel land on one L2
+#include "conv.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDT = BK + 4;  // padded LDS row (dwords)
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    int q = nwg >> 3, r = nwg & 7, x = bid & 7, pos = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + pos;
+}
+
+template <int BN, int WAVES_M, int WAVES_N, bool GATHER>
+__global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int MB = WTM / 32, NB = WTN / 32;
+    constexpr int BL = BN / 32;  // B-tile float4 loads per thread
+    static_assert(WAVES_M * WAVES_N == 4 && MB >= 1 && NB >= 1, "bad tiling");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDT];
+    __shared__ int rowoff[BM];
+    __shared__ float red[2][WAVES_M][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int cls = blockIdx.z;
+    const FvTaps& taps = a.taps[cls];
+
+    const int NT = (a.Nout + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = tile / NT, nt = tile - mt * NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int HWl = a.Hl * a.Wl;
+
+    // output row offsets (in elements) for the epilogue, -1 = row outside the problem
+    if (tid < BM) {
+        int m = m0 + tid, off = -1;
+        if (m < a.M) {
+            int b = m / HWl, rem = m - b * HWl, oh = rem / a.Wl, ow = rem - oh * a.Wl;
+            off = ((b * a.Hout + oh * a.os + a.oph[cls]) * a.Wout + ow * a.os + a.opw[cls]) * a.Nout;
+        }
+        rowoff[tid] = off;
+    }
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto compute = [&](const float* __restrict__ Asm, const float* __restrict__ Bsm) {
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            float4 af[MB], bf[NB];
+            const int ko = kc * 8 + (lane >> 5) * 4;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+                af[i] = *reinterpret_cast<const float4*>(&Asm[(wm * WTM + i * 32 + (lane & 31)) * LDT + ko]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                bf[j] = *reinterpret_cast<const float4*>(&Bsm[(wn * WTN + j * 32 + (lane & 31)) * LDT + ko]);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    if constexpr (GATHER) {
+        // first layer: K = 9*Cin <= 32 gathered element-wise (3x3, pad 1, stride 1), one K step
+        const int Kg = 9 * a.Cin;
+        {
+            const int row = tid >> 1, kb = (tid & 1) * 16;
+            const int m = m0 + row;
+            int b = 0, oh = 0, ow = 0;
+            const bool mv = m < a.M;
+            if (mv) { b = m / HWl; int rem = m - b * HWl; oh = rem / a.Wl; ow = rem - oh * a.Wl; }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int k = kb + e;
+                float v = 0.0f;
+                if (mv && k < Kg) {
+                    int tp = k / a.Cin, c = k - tp * a.Cin;
+                    int ih = oh + tp / 3 - 1, iw = ow + tp % 3 - 1;
+                    if ((unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win)
+                        v = a.x[((size_t)(b * a.Hin + ih) * a.Win + iw) * a.Cin + c];
+                }
+                As[0][row * LDT + k] = v;
+            }
+#pragma unroll
+            for (int p = 0; p < BL; ++p) {
+                int r = (tid >> 3) + 32 * p, n = n0 + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < a.Nout) v = *reinterpret_cast<const float4*>(a.w + (size_t)n * BK + (tid & 7) * 4);
+                *reinterpret_cast<float4*>(&Bs[0][r * LDT + (tid & 7) * 4]) = v;
+            }
+        }
+        __syncthreads();
+        compute(As[0], Bs[0]);
+    } else {
+        const int col4 = (tid & 7) * 4;
+        int a_pix[4], a_oh[4], a_ow[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int m = m0 + (tid >> 3) + 32 * p;
+            if (m < a.M) {
+                int b = m / HWl, rem = m - b * HWl, oh = rem / a.Wl, ow = rem - oh * a.Wl;
+                a_pix[p] = b * a.Hin; a_oh[p] = oh * a.is; a_ow[p] = ow * a.is;
+            } else {
+                a_pix[p] = 0; a_oh[p] = -(1 << 28); a_ow[p] = 0;
+            }
+        }
+        int b_row[BL];
+#pragma unroll
+        for (int p = 0; p < BL; ++p) {
+            int n = n0 + (tid >> 3) + 32 * p;
+            b_row[p] = n < a.Nout ? n * a.Tw * a.Cin : -1;
+        }
+
+        const int cpk = a.Cin / BK;
+        const int nk = taps.n * cpk;
+        float4 ra[4], rb[BL];
+        int a_off[4];
+        int t = 0, ci = 0;
+        auto set_tap = [&](int tp) {
+            const int dh = taps.dh[tp], dw = taps.dw[tp];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                int ih = a_oh[p] + dh, iw = a_ow[p] + dw;
+                bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+                a_off[p] = ok ? ((a_pix[p] + ih) * a.Win + iw) * a.Cin + col4 : -1;
+            }
+        };
+        auto load = [&]() {
+            const int c0 = ci * BK;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                ra[p] = a_off[p] >= 0 ? *reinterpret_cast<const float4*>(a.x + a_off[p] + c0)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int wofs = taps.wslot[t] * a.Cin + c0 + col4;
+#pragma unroll
+            for (int p = 0; p < BL; ++p)
+                rb[p] = b_row[p] >= 0 ? *reinterpret_cast<const float4*>(a.w + b_row[p] + wofs)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        auto stage = [&](int buf) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * p) * LDT + col4]) = ra[p];
+#pragma unroll
+            for (int p = 0; p < BL; ++p)
+                *reinterpret_cast<float4*>(&Bs[buf][((tid >> 3) + 32 * p) * LDT + col4]) = rb[p];
+        };
+        auto advance = [&]() {
+            if (++ci == cpk) { ci = 0; ++t; if (t < taps.n) set_tap(t); }
+        };
+
+        set_tap(0);
+        load();
+        stage(0);
+        advance();
+        __syncthreads();
+        for (int s = 0; s < nk; ++s) {
+            const int cur = s & 1;
+            const bool more = s + 1 < nk;
+            if (more) load();
+            compute(As[cur], Bs[cur]);
+            if (more) { stage(cur ^ 1); advance(); }
+            __syncthreads();
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    const int half = lane >> 5, lc = lane & 31;
+    if (a.epi & FV_EPI_STATS) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { float v = acc[i][j][r]; s += v; q += v * v; }
+            s += __shfl_xor(s, 32);
+            q += __shfl_xor(q, 32);
+            if (half == 0) { red[0][wm][wn * WTN + j * 32 + lc] = s; red[1][wm][wn * WTN + j * 32 + lc] = q; }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Nout) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) { s += red[0][w][tid]; q += red[1][w][tid]; }
+            a.psum[(size_t)mt * a.Nout + n0 + tid] = s;
+            a.psq[(size_t)mt * a.Nout + n0 + tid] = q;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + lc;
+        const bool nv = n < a.Nout;
+        float sc = 1.0f, sh = 0.0f;
+        if ((a.epi & FV_EPI_AFFINE) && nv) {
+            if (a.scale) sc = a.scale[n];
+            if (a.shift) sh = a.shift[n];
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int off = rowoff[row];
+                if (off >= 0 && nv) {
+                    float v = acc[i][j][r];
+                    if (a.epi & FV_EPI_AFFINE) v = v * sc + sh;
+                    if (a.epi & FV_EPI_LEAKY) v = v > 0.0f ? v : v * a.leaky;
+                    if (a.epi & FV_EPI_ADD) v += a.addend[off + n];
+                    a.out[off + n] = v;
+                }
+            }
+    }
+}
+
+template <int BN, int WM_, int WN_, bool G>
+int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
+    const int MT = (a.M + BM - 1) / BM, NT = (a.Nout + BN - 1) / BN;
+    dim3 grid(MT * NT, 1, a.nclass);
+    hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G>), grid, dim3(256), 0, ctx->stream, a);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+}  // namespace
+
+int fv_conv_mtiles(int M, int Nout) { (void)Nout; return (M + BM - 1) / BM; }
+
+int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
+    FV_REQUIRE(ctx, a.x && a.w && a.out, "conv: NULL tensor");
+    FV_REQUIRE(ctx, a.M > 0 && a.Nout > 0 && a.nclass >= 1 && a.nclass <= 4, "conv: bad problem size");
+    FV_REQUIRE(ctx, (long long)a.B * a.Hin * a.Win * a.Cin < (1ll << 31) &&
+                        (long long)a.B * a.Hout * a.Wout * a.Nout < (1ll << 31) &&
+                        (long long)a.Nout * a.Tw * a.Cin < (1ll << 31),
+               "conv: tensor exceeds 2^31 elements");
+    FV_REQUIRE(ctx, !(a.epi & FV_EPI_STATS) || (a.psum && a.psq && a.nclass == 1), "conv: stats need psum/psq");
+    FV_REQUIRE(ctx, !(a.epi & FV_EPI_ADD) || a.addend, "conv: FV_EPI_ADD needs addend");
+    const bool gather = a.Cin % BK != 0;
+    if (gather) {
+        FV_REQUIRE(ctx, 9 * a.Cin <= BK && a.nclass == 1 && a.is == 1 && a.os == 1 && a.taps[0].n == 9 &&
+                            a.Hl == a.Hin && a.Wl == a.Win,
+                   "conv: Cin=%d is only supported as a 3x3 stride-1 pad-1 layer with 9*Cin<=32 "
+                   "(weights packed [n][32])", a.Cin);
+        if (a.Nout > 64) return launch_cfg<128, 2, 2, true>(ctx, a);
+        if (a.Nout > 32) return launch_cfg<64, 2, 2, true>(ctx, a);
+        return launch_cfg<32, 4, 1, true>(ctx, a);
+    }
+    for (int c = 0; c < a.nclass; ++c)
+        FV_REQUIRE(ctx, a.taps[c].n >= 1 && a.taps[c].n <= 9, "conv: bad tap count");
+    if (a.Nout > 64) return launch_cfg<128, 2, 2, false>(ctx, a);
+    if (a.Nout > 32) return launch_cfg<64, 2, 2, false>(ctx, a);
+    return launch_cfg<32, 4, 1, false>(ctx, a);
+}

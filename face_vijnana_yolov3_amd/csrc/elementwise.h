@@ -1,0 +1,20 @@
+// Internal launch interface of elementwise.hip.
+#pragma once
+#include "common.h"
+
+int fv_ew_bn_finalize(fv_ctx* ctx, const float* psum, const float* psq, int mtiles, int C, double count, const float* gamma,
+                      const float* beta, float eps, float momentum, float* mean, float* invstd, float* scale, float* shift,
+                      float* moving_mean, float* moving_var);
+int fv_ew_bn_fold(fv_ctx* ctx, const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C,
+                  float* scale, float* shift);
+int fv_ew_bn_act(fv_ctx* ctx, const float* z, const float* scale, const float* shift, const float* skip, float* out,
+                 long long rows, int C, float leaky);
+int fv_ew_bn_bwd_chunks(long long rows, int C);
+int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale, const float* shift, const float* mean,
+                 const float* invstd, long long rows, int C, float leaky, float* pdb, float* pdg, float* dbeta, float* dgamma,
+                 float* dz);
+int fv_ew_mse(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int Cpad, float* loss, float* dy, float* dbias);
+int fv_ew_adam(fv_ctx* ctx, float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2, float eps);
+int fv_ew_transpose_ntc(fv_ctx* ctx, const float* src, float* dst, int N, int T, int C, int Npad);
+int fv_ew_pad_rows(fv_ctx* ctx, const float* src, float* dst, int N, int K, int Kpad);
+int fv_ew_slice_cols(fv_ctx* ctx, const float* src, float* dst, long long rows, int C, int Cpad);

@@ -1,0 +1,342 @@
+// HBM-bound companions of the conv kernels: training-mode BatchNorm statistics / normalise /
+// LeakyReLU / residual add (reference yolov3_detect.py:212-215), their backward, the MSE loss and
+// its gradient (reference face_detection.py:381), the Keras-formula Adam update
+// (face_detection.py:376-379) and the weight-layout transforms the data-gradient needs.
+// All tensors NHWC float32; 16-byte vector accesses; deterministic reductions (no float atomics).
+#include "elementwise.h"
+
+namespace {
+
+constexpr int RED_ROWS = 32;  // row lanes of the 1024-thread column reducers
+
+// ---------------------------------------------------------------- BN finalize (forward, training)
+// partial sums [mtiles][C] (from the conv epilogue) -> mean, invstd, scale, shift, moving stats.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
+                                                           int mtiles, int C, double count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float momentum,
+                                                           float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                           float* __restrict__ scale_out, float* __restrict__ shift_out,
+                                                           float* __restrict__ moving_mean, float* __restrict__ moving_var) {
+    __shared__ double ssum[RED_ROWS][33], ssq[RED_ROWS][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int r = rl; r < mtiles; r += RED_ROWS) { s += (double)psum[(size_t)r * C + c]; q += (double)psq[(size_t)r * C + c]; }
+    ssum[rl][cl] = s; ssq[rl][cl] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int r = 1; r < RED_ROWS; ++r) { s += ssum[r][cl]; q += ssq[r][cl]; }
+        double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        float g = gamma[c];
+        float sc = g * invstd;
+        mean_out[c] = (float)mean; invstd_out[c] = invstd;
+        scale_out[c] = sc; shift_out[c] = beta[c] - (float)mean * sc;
+        if (moving_mean) {
+            // Keras 2.2.4 BatchNormalization: EMA of batch mean and of var * n/(n-(1+eps))
+            double corr = count / (count - (1.0 + (double)eps));
+            moving_mean[c] = momentum * moving_mean[c] + (1.0f - momentum) * (float)mean;
+            moving_var[c] = momentum * moving_var[c] + (1.0f - momentum) * (float)(var * corr);
+        }
+    }
+}
+
+// inference: fold moving statistics into scale/shift
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                               const float* __restrict__ var, float eps, int C, float* __restrict__ scale, float* __restrict__ shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        float sc = gamma[c] / sqrtf(var[c] + eps);
+        scale[c] = sc; shift[c] = beta[c] - mean[c] * sc;
+    }
+}
+
+// ---------------------------------------------------------------- y = leaky(z*scale+shift) (+ skip)
+__global__ __launch_bounds__(256) void bn_act_kernel(const float4* __restrict__ z, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, const float4* __restrict__ skip,
+                                                     float4* __restrict__ out, long long n4, int C, float leaky) {
+    const int c4n = C >> 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) << 2;
+        float4 v = z[i];
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        v.x = v.x > 0.f ? v.x : v.x * leaky; v.y = v.y > 0.f ? v.y : v.y * leaky;
+        v.z = v.z > 0.f ? v.z : v.z * leaky; v.w = v.w > 0.f ? v.w : v.w * leaky;
+        if (skip) { float4 s = skip[i]; v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+        out[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------- BN + leaky backward
+// pass 1: per-channel partial sums of gy and gy*xhat over a chunk of rows; gy = g * leaky'(y)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            long long M, int C, int rows_per_block, float leaky,
+                                                            float* __restrict__ pdb, float* __restrict__ pdg) {
+    // thread layout: tpr = min(C/4, 256) threads per row, 256/tpr rows in flight
+    __shared__ float4 sdb[256], sdg[256];
+    const int c4n = C >> 2;
+    const int tpr = c4n < 256 ? c4n : 256;
+    const int rpi = 256 / tpr;
+    const int cl = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    for (int cb = cl; cb < c4n; cb += tpr) {
+        const int c = cb << 2;
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+        float4 db = make_float4(0.f, 0.f, 0.f, 0.f), dg = db;
+        for (long long r = r0 + rl; r < r1; r += rpi) {
+            const float4 gv = *reinterpret_cast<const float4*>(g + r * C + c);
+            const float4 zv = *reinterpret_cast<const float4*>(z + r * C + c);
+            float gy;
+            gy = (zv.x * sc.x + sh.x) > 0.f ? gv.x : gv.x * leaky; db.x += gy; dg.x += gy * ((zv.x - mu.x) * is.x);
+            gy = (zv.y * sc.y + sh.y) > 0.f ? gv.y : gv.y * leaky; db.y += gy; dg.y += gy * ((zv.y - mu.y) * is.y);
+            gy = (zv.z * sc.z + sh.z) > 0.f ? gv.z : gv.z * leaky; db.z += gy; dg.z += gy * ((zv.z - mu.z) * is.z);
+            gy = (zv.w * sc.w + sh.w) > 0.f ? gv.w : gv.w * leaky; db.w += gy; dg.w += gy * ((zv.w - mu.w) * is.w);
+        }
+        sdb[threadIdx.x] = db; sdg[threadIdx.x] = dg;
+        __syncthreads();
+        if (rl == 0) {
+            for (int k = 1; k < rpi; ++k) {
+                float4 b = sdb[k * tpr + cl], d = sdg[k * tpr + cl];
+                db.x += b.x; db.y += b.y; db.z += b.z; db.w += b.w;
+                dg.x += d.x; dg.y += d.y; dg.z += d.z; dg.w += d.w;
+            }
+            *reinterpret_cast<float4*>(pdb + (size_t)blockIdx.x * C + c) = db;
+            *reinterpret_cast<float4*>(pdg + (size_t)blockIdx.x * C + c) = dg;
+        }
+        __syncthreads();
+    }
+}
+
+// pass 1b: reduce the chunk partials in double -> dbeta, dgamma (written into the flat grad vector)
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ pdb, const float* __restrict__ pdg,
+                                                               int chunks, int C, float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    __shared__ double s1[RED_ROWS][33], s2[RED_ROWS][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int r = rl; r < chunks; r += RED_ROWS) { a += (double)pdb[(size_t)r * C + c]; b += (double)pdg[(size_t)r * C + c]; }
+    s1[rl][cl] = a; s2[rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int r = 1; r < RED_ROWS; ++r) { a += s1[r][cl]; b += s2[r][cl]; }
+        dbeta[c] = (float)a; dgamma[c] = (float)b;
+    }
+}
+
+// pass 2: dz = scale * (gy - dbeta/M - xhat * dgamma/M)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restrict__ g, const float4* __restrict__ z,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                                           float inv_count, long long n4, int C, float leaky, float4* __restrict__ dz) {
+    const int c4n = C >> 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) << 2;
+        const float4 gv = g[i], zv = z[i];
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+        const float4 db = *reinterpret_cast<const float4*>(dbeta + c), dg = *reinterpret_cast<const float4*>(dgamma + c);
+        float4 o;
+        float gy;
+        gy = (zv.x * sc.x + sh.x) > 0.f ? gv.x : gv.x * leaky; o.x = sc.x * (gy - db.x * inv_count - (zv.x - mu.x) * is.x * (dg.x * inv_count));
+        gy = (zv.y * sc.y + sh.y) > 0.f ? gv.y : gv.y * leaky; o.y = sc.y * (gy - db.y * inv_count - (zv.y - mu.y) * is.y * (dg.y * inv_count));
+        gy = (zv.z * sc.z + sh.z) > 0.f ? gv.z : gv.z * leaky; o.z = sc.z * (gy - db.z * inv_count - (zv.z - mu.z) * is.z * (dg.z * inv_count));
+        gy = (zv.w * sc.w + sh.w) > 0.f ? gv.w : gv.w * leaky; o.w = sc.w * (gy - db.w * inv_count - (zv.w - mu.w) * is.w * (dg.w * inv_count));
+        dz[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------- MSE loss + gradient (single block, deterministic)
+// y_pred/y_true [rows][C]; dy padded [rows][Cpad] with zeros beyond C; bias gradient db[C] = column sums of dy.
+__global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ yp, const float* __restrict__ yt, int rows, int C,
+                                                   int Cpad, float grad_scale, float* __restrict__ loss, float* __restrict__ dy,
+                                                   float* __restrict__ dbias) {
+    __shared__ double sred[1024];
+    __shared__ double scol[1024];
+    const long long n = (long long)rows * C;
+    double acc = 0.0;
+    for (long long i = threadIdx.x; i < (long long)rows * Cpad; i += 1024) {
+        int r = (int)(i / Cpad), c = (int)(i - (long long)r * Cpad);
+        float d = 0.f;
+        if (c < C) { float e = yp[(size_t)r * C + c] - yt[(size_t)r * C + c]; acc += (double)e * (double)e; d = e * grad_scale; }
+        dy[i] = d;
+    }
+    sred[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) { if (threadIdx.x < s) sred[threadIdx.x] += sred[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) *loss = (float)(sred[0] / (double)n);
+    if (dbias) {
+        // column sums: thread = (row lane, column); C <= 32
+        const int cl = threadIdx.x % 32, rl = threadIdx.x / 32;
+        double s = 0.0;
+        if (cl < C) for (int r = rl; r < rows; r += 32) s += (double)((yp[(size_t)r * C + cl] - yt[(size_t)r * C + cl]) * grad_scale);
+        scol[threadIdx.x] = s;
+        __syncthreads();
+        if (rl == 0 && cl < C) { for (int k = 1; k < 32; ++k) s += scol[k * 32 + cl]; dbias[cl] = (float)s; }
+    }
+}
+
+// ---------------------------------------------------------------- Adam (Keras 2.2.4 formula)
+__global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                                   float4* __restrict__ v, long long n4, float lr_t, float b1, float b2, float eps) {
+    const float ob1 = 1.0f - b1, ob2 = 1.0f - b2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 pv = p[i], mv = m[i], vv = v[i];
+        const float4 gv = g[i];
+        mv.x = b1 * mv.x + ob1 * gv.x; mv.y = b1 * mv.y + ob1 * gv.y; mv.z = b1 * mv.z + ob1 * gv.z; mv.w = b1 * mv.w + ob1 * gv.w;
+        vv.x = b2 * vv.x + ob2 * (gv.x * gv.x); vv.y = b2 * vv.y + ob2 * (gv.y * gv.y);
+        vv.z = b2 * vv.z + ob2 * (gv.z * gv.z); vv.w = b2 * vv.w + ob2 * (gv.w * gv.w);
+        pv.x -= lr_t * mv.x / (sqrtf(vv.x) + eps); pv.y -= lr_t * mv.y / (sqrtf(vv.y) + eps);
+        pv.z -= lr_t * mv.z / (sqrtf(vv.z) + eps); pv.w -= lr_t * mv.w / (sqrtf(vv.w) + eps);
+        p[i] = pv; m[i] = mv; v[i] = vv;
+    }
+}
+__global__ void adam_tail_kernel(float* p, const float* g, float* m, float* v, long long begin, long long n, float lr_t, float b1,
+                                 float b2, float eps) {
+    long long i = begin + blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i < n) {
+        float mv = b1 * m[i] + (1.0f - b1) * g[i];
+        float vv = b2 * v[i] + (1.0f - b2) * (g[i] * g[i]);
+        p[i] -= lr_t * mv / (sqrtf(vv) + eps);
+        m[i] = mv; v[i] = vv;
+    }
+}
+
+// ---------------------------------------------------------------- weight layout transforms
+// src [N][T][C] -> dst [C][T][Npad] (zero padded), tiled through LDS so both sides are coalesced.
+__global__ __launch_bounds__(256) void transpose_ntc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int T,
+                                                            int C, int Npad) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int n0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        int n = n0 + k, c = c0 + tx;
+        tile[k][tx] = (n < N && c < C) ? src[((size_t)n * T + t) * C + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        int c = c0 + k, n = n0 + tx;
+        if (c < C && n < Npad) dst[((size_t)c * T + t) * Npad + n] = tile[tx][k];
+    }
+}
+
+// first-layer kernel [N][K] (K = 27) -> [N][32] zero padded (the gather conv's B operand)
+__global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int K, int Kpad) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N * Kpad) { int n = i / Kpad, k = i - n * Kpad; dst[i] = k < K ? src[n * K + k] : 0.0f; }
+}
+
+// out[rows][C] = in[rows][Cpad][:C]
+__global__ void slice_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, long long rows, int C, int Cpad) {
+    long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i < rows * C) { long long r = i / C; int c = (int)(i - r * C); dst[i] = src[r * Cpad + c]; }
+}
+
+inline int grid_for(long long n, int block, int cap = 256 * 8) {
+    long long g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+int fv_ew_bn_finalize(fv_ctx* ctx, const float* psum, const float* psq, int mtiles, int C, double count, const float* gamma,
+                      const float* beta, float eps, float momentum, float* mean, float* invstd, float* scale, float* shift,
+                      float* moving_mean, float* moving_var) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, ctx->stream, psum, psq, mtiles, C, count, gamma,
+                       beta, eps, momentum, mean, invstd, scale, shift, moving_mean, moving_var);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_ew_bn_fold(fv_ctx* ctx, const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C,
+                  float* scale, float* shift) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, gamma, beta, mean, var, eps, C, scale, shift);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_ew_bn_act(fv_ctx* ctx, const float* z, const float* scale, const float* shift, const float* skip, float* out,
+                 long long rows, int C, float leaky) {
+    FV_REQUIRE(ctx, C % 4 == 0, "bn_act: C must be a multiple of 4");
+    long long n4 = rows * C / 4;
+    hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, ctx->stream, (const float4*)z, scale, shift,
+                       (const float4*)skip, (float4*)out, n4, C, leaky);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_ew_bn_bwd_chunks(long long rows, int C) {
+    // ~2048 blocks, at least 64 rows each
+    long long rpb = (rows + 2047) / 2048;
+    if (rpb < 64) rpb = 64;
+    return (int)((rows + rpb - 1) / rpb);
+}
+
+int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale, const float* shift, const float* mean,
+                 const float* invstd, long long rows, int C, float leaky, float* pdb, float* pdg, float* dbeta, float* dgamma,
+                 float* dz) {
+    FV_REQUIRE(ctx, C % 4 == 0, "bn_bwd: C must be a multiple of 4");
+    long long rpb = (rows + 2047) / 2048;
+    if (rpb < 64) rpb = 64;
+    int chunks = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(chunks), dim3(256), 0, ctx->stream, g, z, scale, shift, mean, invstd, rows, C,
+                       (int)rpb, leaky, pdb, pdg);
+    FV_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, ctx->stream, pdb, pdg, chunks, C, dbeta, dgamma);
+    FV_LAUNCH_CHECK(ctx);
+    long long n4 = rows * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, ctx->stream, (const float4*)g, (const float4*)z,
+                       scale, shift, mean, invstd, dbeta, dgamma, (float)(1.0 / (double)rows), n4, C, leaky, (float4*)dz);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_ew_mse(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int Cpad, float* loss, float* dy, float* dbias) {
+    FV_REQUIRE(ctx, C <= 32 && Cpad >= C, "mse: C must be <= 32");
+    float gs = (float)(2.0 / ((double)rows * C));
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, ctx->stream, yp, yt, rows, C, Cpad, gs, loss, dy, dbias);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_ew_adam(fv_ctx* ctx, float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2, float eps) {
+    long long n4 = n / 4;
+    if (n4 > 0) {
+        hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4, 256, 256 * 16)), dim3(256), 0, ctx->stream, (float4*)p, (const float4*)g,
+                           (float4*)m, (float4*)v, n4, lr_t, b1, b2, eps);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    if (n4 * 4 < n) {
+        hipLaunchKernelGGL(adam_tail_kernel, dim3(1), dim3(64), 0, ctx->stream, p, g, m, v, n4 * 4, n, lr_t, b1, b2, eps);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    return FV_OK;
+}
+
+int fv_ew_transpose_ntc(fv_ctx* ctx, const float* src, float* dst, int N, int T, int C, int Npad) {
+    hipLaunchKernelGGL(transpose_ntc_kernel, dim3((C + 31) / 32, (Npad + 31) / 32, T), dim3(256), 0, ctx->stream, src, dst, N, T, C, Npad);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_ew_pad_rows(fv_ctx* ctx, const float* src, float* dst, int N, int K, int Kpad) {
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((N * Kpad + 255) / 256), dim3(256), 0, ctx->stream, src, dst, N, K, Kpad);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_ew_slice_cols(fv_ctx* ctx, const float* src, float* dst, long long rows, int C, int Cpad) {
+    hipLaunchKernelGGL(slice_cols_kernel, dim3((unsigned)((rows * C + 255) / 256)), dim3(256), 0, ctx->stream, src, dst, rows, C, Cpad);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}

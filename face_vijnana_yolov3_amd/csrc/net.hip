@@ -1,0 +1,266 @@
+// Network-level schedule: the FaceDetector model (Darknet-53 base as wired by reference
+// face_detection.py:404-593 over yolov3_detect.py:221-267, head face_detection.py:348-352),
+// inference forward and the training step (forward, MSE, backward) as a fixed sequence of kernel
+// launches on one HIP stream.  The layer table is derived here from the stage structure
+// (filters, residual blocks) rather than transcribed.
+#include <vector>
+#include "conv.h"
+#include "elementwise.h"
+#include "ops.h"
+
+namespace {
+
+constexpr float BN_EPS = 1e-3f;       // yd.py:212
+constexpr float BN_MOMENTUM = 0.99f;  // Keras BatchNormalization default
+constexpr float LEAKY = 0.1f;         // yd.py:213
+constexpr int HEAD_C = 6;             // nn_arch.bb_info_c_size
+constexpr int HEAD_PAD = 32;
+
+struct Net {
+    std::vector<fv_layer_desc> L;
+    int64_t nparam = 0, nstate = 0;
+    Net() {
+        auto add = [&](int idx, int k, int s, int cin, int cout, int role, int in_div) {
+            fv_layer_desc d{};
+            d.darknet_index = idx; d.ksize = k; d.stride = s; d.cin = cin; d.cout = cout; d.has_bn = 1; d.role = role;
+            d.in_div = in_div; d.out_div = in_div * s;
+            d.w_off = nparam; nparam += (int64_t)cout * k * k * cin;
+            d.gamma_off = nparam; nparam += cout;
+            d.beta_off = nparam; nparam += cout;
+            d.mean_off = nstate; nstate += cout;
+            d.var_off = nstate; nstate += cout;
+            L.push_back(d);
+        };
+        int idx = 0, div = 1, cin = 32;
+        add(idx++, 3, 1, 3, 32, 0, div);
+        const int stages[5][2] = {{64, 1}, {128, 2}, {256, 8}, {512, 8}, {1024, 4}};
+        for (auto& st : stages) {
+            const int cout = st[0];
+            add(idx++, 3, 2, cin, cout, 0, div);
+            div *= 2;
+            for (int b = 0; b < st[1]; ++b) {
+                add(idx++, 1, 1, cout, cout / 2, 1, div);
+                add(idx++, 3, 1, cout / 2, cout, 2, div);
+                ++idx;  // the Darknet shortcut layer owns an index
+            }
+            cin = cout;
+        }
+        fv_layer_desc h{};
+        h.darknet_index = -1; h.ksize = 3; h.stride = 1; h.cin = 1024; h.cout = HEAD_C; h.has_bn = 0; h.role = 3;
+        h.in_div = div; h.out_div = div;
+        h.w_off = nparam; nparam += (int64_t)HEAD_C * 9 * 1024;
+        h.gamma_off = -1; h.beta_off = nparam; nparam += HEAD_C;
+        h.mean_off = h.var_off = -1;
+        L.push_back(h);
+    }
+};
+const Net& net() { static Net n; return n; }
+
+struct Carver {
+    char* base; size_t off = 0;
+    explicit Carver(void* b) : base((char*)b) {}
+    float* take(size_t floats) {
+        float* p = base ? (float*)(base + off) : nullptr;
+        off += (floats * sizeof(float) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+
+struct Plan {
+    int B, S, nl;
+    std::vector<float*> z, a, mean, invstd, scale, shift, wt;
+    float *psum, *psq, *pdb, *pdg, *w0p, *yhat, *dyp, *G[3], *loss;
+    size_t bytes;
+};
+
+// Carve the workspace (base == NULL: size query only).
+Plan make_plan(void* base, int B, int S, bool training) {
+    const Net& N = net();
+    Plan p{};
+    p.B = B; p.S = S; p.nl = (int)N.L.size();
+    Carver c(base);
+    const int nb = p.nl - 1;
+    p.z.resize(nb); p.a.resize(nb); p.mean.resize(nb); p.invstd.resize(nb); p.scale.resize(nb); p.shift.resize(nb);
+    p.wt.resize(p.nl);
+    size_t max_act = 0, max_part = 0, max_bwd = 0;
+    for (int l = 0; l < nb; ++l) {
+        const auto& d = N.L[l];
+        size_t hw = (size_t)(S / d.out_div) * (S / d.out_div);
+        size_t rows = (size_t)B * hw, elems = rows * d.cout;
+        if (elems > max_act) max_act = elems;
+        size_t part = (size_t)fv_conv_mtiles((int)rows, d.cout) * d.cout;
+        if (part > max_part) max_part = part;
+        size_t bw = (size_t)fv_ew_bn_bwd_chunks((long long)rows, d.cout) * d.cout;
+        if (bw > max_bwd) max_bwd = bw;
+    }
+    for (int l = 0; l < nb; ++l) {
+        const auto& d = N.L[l];
+        p.scale[l] = c.take(d.cout); p.shift[l] = c.take(d.cout);
+        if (training) { p.mean[l] = c.take(d.cout); p.invstd[l] = c.take(d.cout); }
+    }
+    p.w0p = c.take(32 * 32);
+    const int G = S / 32;
+    p.yhat = c.take((size_t)B * G * G * HEAD_C);
+    if (training) {
+        for (int l = 0; l < nb; ++l) {
+            const auto& d = N.L[l];
+            size_t elems = (size_t)B * (S / d.out_div) * (S / d.out_div) * d.cout;
+            p.z[l] = c.take(elems); p.a[l] = c.take(elems);
+        }
+        for (int l = 1; l < p.nl; ++l) {
+            const auto& d = N.L[l];
+            int cp = d.has_bn ? d.cout : HEAD_PAD;
+            p.wt[l] = c.take((size_t)d.cin * d.ksize * d.ksize * cp);
+        }
+        p.psum = c.take(max_part); p.psq = c.take(max_part);
+        p.pdb = c.take(max_bwd); p.pdg = c.take(max_bwd);
+        p.dyp = c.take((size_t)B * G * G * HEAD_PAD);
+        for (int i = 0; i < 3; ++i) p.G[i] = c.take(max_act);
+        p.loss = c.take(64);
+    } else {
+        for (int i = 0; i < 3; ++i) p.G[i] = c.take(max_act);
+    }
+    p.bytes = c.off;
+    return p;
+}
+
+int check_shape(fv_ctx* ctx, int batch, int S) {
+    FV_REQUIRE(ctx, batch >= 1 && S >= 32 && S % 32 == 0, "image_size must be a positive multiple of 32 (got %d), batch >= 1", S);
+    FV_REQUIRE(ctx, (long long)batch * S * S * 32 < (1ll << 31), "batch*S*S*32 exceeds 2^31 elements; reduce the per-GPU batch");
+    return FV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fv_num_layers(void) { return (int)net().L.size(); }
+int fv_layer(int i, fv_layer_desc* out) {
+    if (!out || i < 0 || i >= (int)net().L.size()) return FV_ERR_INVALID;
+    *out = net().L[i];
+    return FV_OK;
+}
+int64_t fv_param_count(void) { return net().nparam; }
+int64_t fv_state_count(void) { return net().nstate; }
+
+size_t fv_workspace_bytes(int batch, int image_size, int training) {
+    if (batch < 1 || image_size < 32 || image_size % 32) return 0;
+    return make_plan(nullptr, batch, image_size, training != 0).bytes;
+}
+
+int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, const float* x, int batch, int image_size,
+                     void* workspace, size_t workspace_bytes, float* y) {
+    if (!ctx) return FV_ERR_INVALID;
+    FV_REQUIRE(ctx, params && bn_state && x && workspace && y, "forward_infer: NULL buffer");
+    if (int rc = check_shape(ctx, batch, image_size)) return rc;
+    Plan p = make_plan(workspace, batch, image_size, false);
+    if (p.bytes > workspace_bytes) return fv_fail(ctx, FV_ERR_WORKSPACE, "forward_infer: workspace %zu < %zu bytes", workspace_bytes, p.bytes);
+    const Net& N = net();
+    const int nb = p.nl - 1;
+    for (int l = 0; l < nb; ++l) {
+        const auto& d = N.L[l];
+        if (int rc = fv_ew_bn_fold(ctx, params + d.gamma_off, params + d.beta_off, bn_state + d.mean_off, bn_state + d.var_off,
+                                   BN_EPS, d.cout, p.scale[l], p.shift[l])) return rc;
+    }
+    if (int rc = fv_ew_pad_rows(ctx, params + N.L[0].w_off, p.w0p, 32, 27, 32)) return rc;
+    // rotating buffers: cur (input), skip (kept while a residual block runs), out
+    const float* cur = x;
+    int icur = -1, iskip = -1;
+    const float* skip = nullptr;
+    for (int l = 0; l < nb; ++l) {
+        const auto& d = N.L[l];
+        const int H = image_size / d.in_div;
+        if (d.role == 1) { skip = cur; iskip = icur; }
+        int iout = 0;
+        while (iout == icur || (iout == iskip && (d.role == 1 || d.role == 2))) ++iout;
+        float* out = p.G[iout];
+        const float* w = l == 0 ? p.w0p : params + d.w_off;
+        int epi = FV_EPI_AFFINE | FV_EPI_LEAKY | (d.role == 2 ? FV_EPI_ADD : 0);
+        if (int rc = fv_op_conv_forward(ctx, cur, w, batch, H, H, d.cin, d.cout, d.ksize, d.stride, epi, p.scale[l], p.shift[l],
+                                        LEAKY, d.role == 2 ? skip : nullptr, out, nullptr, nullptr)) return rc;
+        cur = out; icur = iout;
+        if (d.role == 2) { skip = nullptr; iskip = -1; }
+    }
+    const auto& h = N.L[nb];
+    const int G = image_size / h.in_div;
+    return fv_op_conv_forward(ctx, cur, params + h.w_off, batch, G, G, h.cin, h.cout, 3, 1, FV_EPI_AFFINE, nullptr,
+                              params + h.beta_off, 0.f, nullptr, y, nullptr, nullptr);
+}
+
+int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float* x, const float* y_true, int batch,
+                  int image_size, void* workspace, size_t workspace_bytes, float* grads, float* loss, fv_bucket_fn on_bucket,
+                  void* user) {
+    if (!ctx) return FV_ERR_INVALID;
+    FV_REQUIRE(ctx, params && bn_state && x && y_true && workspace && grads && loss, "train_step: NULL buffer");
+    if (int rc = check_shape(ctx, batch, image_size)) return rc;
+    Plan p = make_plan(workspace, batch, image_size, true);
+    if (p.bytes > workspace_bytes) return fv_fail(ctx, FV_ERR_WORKSPACE, "train_step: workspace %zu < %zu bytes", workspace_bytes, p.bytes);
+    const Net& N = net();
+    const int nb = p.nl - 1;
+    const int S = image_size;
+
+    FV_HIP(ctx, hipMemsetAsync(grads, 0, (size_t)N.nparam * sizeof(float), ctx->stream));
+    // weight images for this step: packed first layer, transposed kernels for the data-gradients
+    if (int rc = fv_ew_pad_rows(ctx, params + N.L[0].w_off, p.w0p, 32, 27, 32)) return rc;
+    for (int l = 1; l < p.nl; ++l) {
+        const auto& d = N.L[l];
+        if (int rc = fv_ew_transpose_ntc(ctx, params + d.w_off, p.wt[l], d.cout, d.ksize * d.ksize, d.cin, d.has_bn ? d.cout : HEAD_PAD)) return rc;
+    }
+
+    // ---------------- forward (training-mode BN)
+    const float* cur = x;
+    const float* skip = nullptr;
+    for (int l = 0; l < nb; ++l) {
+        const auto& d = N.L[l];
+        const int H = S / d.in_div, Ho = S / d.out_div;
+        const long long rows = (long long)batch * Ho * Ho;
+        if (d.role == 1) skip = cur;
+        const float* w = l == 0 ? p.w0p : params + d.w_off;
+        if (int rc = fv_op_conv_forward(ctx, cur, w, batch, H, H, d.cin, d.cout, d.ksize, d.stride, FV_EPI_STATS, nullptr, nullptr,
+                                        0.f, nullptr, p.z[l], p.psum, p.psq)) return rc;
+        if (int rc = fv_ew_bn_finalize(ctx, p.psum, p.psq, fv_conv_mtiles((int)rows, d.cout), d.cout, (double)rows,
+                                       params + d.gamma_off, params + d.beta_off, BN_EPS, BN_MOMENTUM, p.mean[l], p.invstd[l],
+                                       p.scale[l], p.shift[l], bn_state + d.mean_off, bn_state + d.var_off)) return rc;
+        if (int rc = fv_ew_bn_act(ctx, p.z[l], p.scale[l], p.shift[l], d.role == 2 ? skip : nullptr, p.a[l], rows, d.cout, LEAKY)) return rc;
+        cur = p.a[l];
+    }
+    const auto& h = N.L[nb];
+    const int G = S / h.in_div;
+    const int hrows = batch * G * G;
+    if (int rc = fv_op_conv_forward(ctx, cur, params + h.w_off, batch, G, G, h.cin, h.cout, 3, 1, FV_EPI_AFFINE, nullptr,
+                                    params + h.beta_off, 0.f, nullptr, p.yhat, nullptr, nullptr)) return rc;
+    // ---------------- loss + its gradient (fd.py:381 'mse')
+    if (int rc = fv_ew_mse(ctx, p.yhat, y_true, hrows, HEAD_C, HEAD_PAD, loss, p.dyp, grads + h.beta_off)) return rc;
+
+    // ---------------- backward
+    if (int rc = fv_op_conv_wgrad(ctx, p.a[nb - 1], p.dyp, batch, G, G, h.cin, h.cout, HEAD_PAD, 3, 1, grads + h.w_off)) return rc;
+    if (int rc = fv_op_conv_dgrad(ctx, p.dyp, p.wt[nb], batch, G, G, h.cin, HEAD_PAD, 3, 1, nullptr, p.G[0])) return rc;
+    if (on_bucket) on_bucket(user, h.w_off, (int64_t)HEAD_C * 9 * 1024 + HEAD_C);
+    // G[ig]: gradient w.r.t. the current layer's (post-add) output; G[ires]: kept block gradient
+    int ig = 0, ires = -1;
+    for (int l = nb - 1; l >= 0; --l) {
+        const auto& d = N.L[l];
+        const int H = S / d.in_div, Ho = S / d.out_div;
+        const long long rows = (long long)batch * Ho * Ho;
+        int idz = 0;
+        while (idz == ig || idz == ires) ++idz;
+        float* dz = p.G[idz];
+        if (d.role == 2) ires = ig;  // add(skip, x): the same gradient also reaches the skip input
+        if (int rc = fv_ew_bn_bwd(ctx, p.G[ig], p.z[l], p.scale[l], p.shift[l], p.mean[l], p.invstd[l], rows, d.cout, LEAKY,
+                                  p.pdb, p.pdg, grads + d.beta_off, grads + d.gamma_off, dz)) return rc;
+        const float* xin = l == 0 ? x : p.a[l - 1];
+        if (int rc = fv_op_conv_wgrad(ctx, xin, dz, batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off)) return rc;
+        if (on_bucket) on_bucket(user, d.w_off, (int64_t)d.cout * d.ksize * d.ksize * d.cin + 2 * d.cout);
+        if (l == 0) break;
+        // dgrad writes over the consumed gradient buffer G[ig] (bn_bwd has read it), unless that
+        // buffer is the kept block gradient
+        int iout = (ig == ires) ? 3 - idz - ig : ig;
+        const float* addend = d.role == 1 ? p.G[ires] : nullptr;
+        if (int rc = fv_op_conv_dgrad(ctx, dz, p.wt[l], batch, H, H, d.cin, d.cout, d.ksize, d.stride, addend, p.G[iout])) return rc;
+        ig = iout;
+        if (d.role == 1) ires = -1;
+    }
+    return FV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,170 @@
+// Operator-level entry points of the C ABI: translate Keras-style conv descriptions into the
+// gather-convolution tap lists of conv.h.
+#include "conv.h"
+#include "elementwise.h"
+#include "ops.h"
+
+static void fwd_taps(int ksize, FvTaps& t) {
+    if (ksize == 1) { t.n = 1; t.dh[0] = t.dw[0] = 0; t.wslot[0] = 0; return; }
+    t.n = 9;
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q) { int i = r * 3 + q; t.dh[i] = r - 1; t.dw[i] = q - 1; t.wslot[i] = i; }
+}
+
+int fv_op_conv_forward(fv_ctx* ctx, const float* x, const float* w, int B, int H, int W, int cin, int cout, int ksize,
+                       int stride, int epi, const float* scale, const float* shift, float leaky, const float* addend,
+                       float* out, float* psum, float* psq) {
+    FV_REQUIRE(ctx, (ksize == 1 && stride == 1) || (ksize == 3 && (stride == 1 || stride == 2)), "conv: unsupported k=%d s=%d", ksize, stride);
+    FV_REQUIRE(ctx, H % stride == 0 && W % stride == 0, "conv: H,W must be divisible by the stride");
+    FvConvArgs a{};
+    a.x = x; a.w = w; a.out = out; a.addend = addend; a.scale = scale; a.shift = shift; a.psum = psum; a.psq = psq;
+    a.B = B; a.Hin = H; a.Win = W; a.Cin = cin;
+    a.Hl = H / stride; a.Wl = W / stride; a.Hout = a.Hl; a.Wout = a.Wl; a.Nout = cout;
+    a.is = stride; a.os = 1; a.Tw = ksize * ksize; a.M = B * a.Hl * a.Wl;
+    a.epi = epi; a.leaky = leaky; a.nclass = 1;
+    fwd_taps(ksize, a.taps[0]);
+    if (cin % 32 != 0) a.Tw = 1;  // packed [cout][32] first-layer weights
+    return fv_conv_launch(ctx, a);
+}
+
+int fv_op_conv_dgrad(fv_ctx* ctx, const float* dy, const float* w_t, int B, int H, int W, int cin, int cout_pad, int ksize,
+                     int stride, const float* addend, float* dx) {
+    FV_REQUIRE(ctx, (ksize == 1 && stride == 1) || (ksize == 3 && (stride == 1 || stride == 2)), "dgrad: unsupported k=%d s=%d", ksize, stride);
+    FV_REQUIRE(ctx, cout_pad % 32 == 0, "dgrad: cout_pad must be a multiple of 32");
+    FV_REQUIRE(ctx, H % stride == 0 && W % stride == 0, "dgrad: H,W must be divisible by the stride");
+    FvConvArgs a{};
+    a.x = dy; a.w = w_t; a.out = dx; a.addend = addend;
+    a.B = B; a.Hin = H / stride; a.Win = W / stride; a.Cin = cout_pad;
+    a.Hout = H; a.Wout = W; a.Nout = cin;
+    a.is = 1; a.Tw = ksize * ksize;
+    a.epi = addend ? FV_EPI_ADD : 0; a.leaky = 0.f;
+    if (stride == 1) {
+        a.Hl = H; a.Wl = W; a.os = 1; a.nclass = 1;
+        FvTaps& t = a.taps[0];
+        if (ksize == 1) { t.n = 1; t.dh[0] = t.dw[0] = 0; t.wslot[0] = 0; }
+        else {
+            t.n = 9;   // dx[h] = sum_r dz[h + 1 - r] w[r]
+            for (int r = 0; r < 3; ++r)
+                for (int q = 0; q < 3; ++q) { int i = r * 3 + q; t.dh[i] = 1 - r; t.dw[i] = 1 - q; t.wslot[i] = i; }
+        }
+    } else {
+        // forward: z[oh] reads x[2 oh - 1 + r].  Output pixel h = 2a+ph receives from r with
+        // (h+1-r) even: ph=0 -> r=1 (oh=a); ph=1 -> r=0 (oh=a+1), r=2 (oh=a).  One class per (ph,pw).
+        FV_REQUIRE(ctx, H % 2 == 0 && W % 2 == 0, "dgrad: stride 2 needs even H, W");
+        a.Hl = H / 2; a.Wl = W / 2; a.os = 2; a.nclass = 4;
+        for (int ph = 0; ph < 2; ++ph)
+            for (int pw = 0; pw < 2; ++pw) {
+                int c = ph * 2 + pw;
+                a.oph[c] = ph; a.opw[c] = pw;
+                FvTaps& t = a.taps[c];
+                t.n = 0;
+                for (int r = 0; r < 3; ++r) {
+                    if ((ph + 1 - r) % 2 != 0) continue;
+                    for (int q = 0; q < 3; ++q) {
+                        if ((pw + 1 - q) % 2 != 0) continue;
+                        t.dh[t.n] = (ph + 1 - r) / 2; t.dw[t.n] = (pw + 1 - q) / 2; t.wslot[t.n] = r * 3 + q;
+                        ++t.n;
+                    }
+                }
+            }
+    }
+    a.M = B * a.Hl * a.Wl;
+    return fv_conv_launch(ctx, a);
+}
+
+int fv_op_conv_wgrad(fv_ctx* ctx, const float* x, const float* dy, int B, int H, int W, int cin, int cout, int dy_stride,
+                     int ksize, int stride, float* dw) {
+    FV_REQUIRE(ctx, (ksize == 1 && stride == 1) || (ksize == 3 && (stride == 1 || stride == 2)), "wgrad: unsupported k=%d s=%d", ksize, stride);
+    FvWgradArgs a{};
+    a.x = x; a.dy = dy; a.dw = dw;
+    a.B = B; a.Hin = H; a.Win = W; a.Cin = cin;
+    a.Hl = H / stride; a.Wl = W / stride; a.N = cout; a.Ndy = dy_stride;
+    a.is = stride; a.Tw = ksize * ksize; a.M = B * a.Hl * a.Wl;
+    fwd_taps(ksize, a.taps);
+    return fv_wgrad_launch(ctx, a);
+}
+
+extern "C" {
+
+int fv_conv2d_stat_rows(int64_t out_pixels) { return fv_conv_mtiles((int)out_pixels, 0); }
+
+int fv_conv2d_forward(fv_ctx* ctx, const float* x, const float* w, int B, int H, int W, int cin, int cout, int ksize,
+                      int stride, const float* scale, const float* shift, float leaky, const float* addend, float* out,
+                      float* psum, float* psq) {
+    if (!ctx) return FV_ERR_INVALID;
+    int epi = 0;
+    if (psum) {
+        FV_REQUIRE(ctx, !scale && !shift && !addend && leaky < 0.f, "conv2d_forward: statistics mode stores the raw result");
+        epi = FV_EPI_STATS;
+    } else {
+        if (scale || shift) epi |= FV_EPI_AFFINE;
+        if (leaky >= 0.f) epi |= FV_EPI_LEAKY;
+        if (addend) epi |= FV_EPI_ADD;
+    }
+    return fv_op_conv_forward(ctx, x, w, B, H, W, cin, cout, ksize, stride, epi, scale, shift, leaky, addend, out, psum, psq);
+}
+
+int fv_conv2d_dgrad(fv_ctx* ctx, const float* dy, const float* w_t, int B, int H, int W, int cin, int cout_pad, int ksize,
+                    int stride, const float* addend, float* dx) {
+    if (!ctx) return FV_ERR_INVALID;
+    return fv_op_conv_dgrad(ctx, dy, w_t, B, H, W, cin, cout_pad, ksize, stride, addend, dx);
+}
+
+int fv_conv2d_wgrad(fv_ctx* ctx, const float* x, const float* dy, int B, int H, int W, int cin, int cout, int dy_stride,
+                    int ksize, int stride, float* dw) {
+    if (!ctx) return FV_ERR_INVALID;
+    return fv_op_conv_wgrad(ctx, x, dy, B, H, W, cin, cout, dy_stride, ksize, stride, dw);
+}
+
+int fv_transpose_weights(fv_ctx* ctx, const float* w, int cout, int taps, int cin, int cout_pad, float* w_t) {
+    if (!ctx) return FV_ERR_INVALID;
+    FV_REQUIRE(ctx, cout_pad >= cout, "transpose_weights: cout_pad < cout");
+    return fv_ew_transpose_ntc(ctx, w, w_t, cout, taps, cin, cout_pad);
+}
+
+int fv_pack_first_layer(fv_ctx* ctx, const float* w, int cout, int k_elems, float* w_packed) {
+    if (!ctx) return FV_ERR_INVALID;
+    FV_REQUIRE(ctx, k_elems <= 32, "pack_first_layer: k_elems > 32");
+    return fv_ew_pad_rows(ctx, w, w_packed, cout, k_elems, 32);
+}
+
+int fv_bn_finalize(fv_ctx* ctx, const float* psum, const float* psq, int stat_rows, int C, int64_t count, const float* gamma,
+                   const float* beta, float eps, float momentum, float* mean, float* invstd, float* scale, float* shift,
+                   float* moving_mean, float* moving_var) {
+    if (!ctx) return FV_ERR_INVALID;
+    return fv_ew_bn_finalize(ctx, psum, psq, stat_rows, C, (double)count, gamma, beta, eps, momentum, mean, invstd, scale, shift,
+                             moving_mean, moving_var);
+}
+
+int fv_bn_act(fv_ctx* ctx, const float* z, const float* scale, const float* shift, const float* skip, float* out, int64_t rows,
+              int C, float leaky) {
+    if (!ctx) return FV_ERR_INVALID;
+    return fv_ew_bn_act(ctx, z, scale, shift, skip, out, rows, C, leaky);
+}
+
+int64_t fv_bn_bwd_scratch_floats(int64_t rows, int C) { return (int64_t)fv_ew_bn_bwd_chunks(rows, C) * C; }
+
+int fv_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale, const float* shift, const float* mean,
+              const float* invstd, int64_t rows, int C, float leaky, float* scratch, float* dbeta, float* dgamma, float* dz) {
+    if (!ctx) return FV_ERR_INVALID;
+    int64_t half = fv_bn_bwd_scratch_floats(rows, C);
+    return fv_ew_bn_bwd(ctx, g, z, scale, shift, mean, invstd, rows, C, leaky, scratch, scratch + half, dbeta, dgamma, dz);
+}
+
+int fv_mse_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int c_pad, float* loss, float* dy,
+                     float* dbias) {
+    if (!ctx) return FV_ERR_INVALID;
+    return fv_ew_mse(ctx, yp, yt, rows, C, c_pad, loss, dy, dbias);
+}
+
+int fv_adam_step(fv_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n, int64_t iteration, double lr,
+                 double beta_1, double beta_2, double eps, double decay) {
+    if (!ctx) return FV_ERR_INVALID;
+    FV_REQUIRE(ctx, params && grads && m && v && n > 0, "adam: NULL buffer");
+    if (decay > 0.0) lr = lr * (1.0 / (1.0 + decay * (double)iteration));
+    double t = (double)iteration + 1.0;
+    double lr_t = lr * (sqrt(1.0 - pow(beta_2, t)) / (1.0 - pow(beta_1, t)));
+    return fv_ew_adam(ctx, params, grads, m, v, n, (float)lr_t, (float)beta_1, (float)beta_2, (float)eps);
+}
+
+}  // extern "C"

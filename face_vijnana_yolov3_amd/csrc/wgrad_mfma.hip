@@ -1,0 +1,204 @@
+// fp32 weight-gradient of the gather-convolution on CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   dw[n][wslot[t]][c] += sum over lattice pixels m of  dy[m][n] * x[pixel(m, t)][c]
+//
+// Replaces the conv-kernel gradients TF autodiff produces inside Keras `fit_generator`
+// (reference face_detection.py:621-627) for every conv of yolov3_detect.py:221-267 and the head.
+//
+// GEMM view per tap: M' = output channels n, N' = input channels c, K' = pixels.  Both operand
+// tiles are read as pixel rows (channels contiguous in NHWC), staged [pixel][channel] in LDS and
+// consumed with conflict-free ds_read_b32 (32 consecutive dwords per lane half).
+//  * QUAD  (128x128 tile): 2x2 waves, each a 64x64 sub-tile over all 32 pixels of a chunk
+//  * split (32/64 tiles) : every wave owns the whole tile over its quarter of the pixel chunk
+//  * grid = (tiles x taps, K-splits); partial tiles are added with float atomics shaped as two
+//    128-byte row segments per wave instruction; the caller zeroes dw once per step
+#include "conv.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int KP = 32;  // pixels per chunk
+
+template <int TM, int TN, bool QUAD, bool GATHER>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int chunks_per_split, int ntap_eff) {
+    constexpr int LDA = TM + 4, LDB = TN + 4;  // +4 keeps 16-byte row alignment for the staged float4 writes
+    constexpr int WTM = QUAD ? TM / 2 : TM, WTN = QUAD ? TN / 2 : TN;
+    constexpr int MB = WTM / 32, NB = WTN / 32;
+    constexpr int AL = TM * KP / 4 / 256, BL = TN * KP / 4 / 256;  // float4 loads per thread (>=1)
+    static_assert(AL >= 1 && BL >= 1, "tile too small for 256 threads");
+
+    __shared__ __attribute__((aligned(16))) float As[2][KP * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][KP * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = QUAD ? (wave >> 1) : 0, wn = QUAD ? (wave & 1) : 0;
+    const int NTc = GATHER ? 1 : a.Cin / TN;
+    int bid = blockIdx.x;
+    const int tp = bid % ntap_eff; bid /= ntap_eff;   // taps fastest: tap blocks of one tile share dy in L2
+    const int ct = bid % NTc, nt = bid / NTc;
+    const int n0 = nt * TM, c0 = ct * TN;
+    const int HWl = a.Hl * a.Wl;
+    const int dh = GATHER ? 0 : a.taps.dh[tp], dw = GATHER ? 0 : a.taps.dw[tp];
+
+    const int total_chunks = (a.M + KP - 1) / KP;
+    const int ch_begin = blockIdx.y * chunks_per_split;
+    const int ch_end = min(total_chunks, ch_begin + chunks_per_split);
+    if (ch_begin >= ch_end) return;
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ra[AL], rb[BL];
+    auto load = [&](int ch) {
+        const int mbase = ch * KP;
+#pragma unroll
+        for (int p = 0; p < AL; ++p) {
+            int f = tid + 256 * p, row = f / (TM / 4), col = (f % (TM / 4)) * 4;
+            int m = mbase + row, n = n0 + col;
+            ra[p] = (m < a.M && n < a.N) ? *reinterpret_cast<const float4*>(a.dy + (size_t)m * a.Ndy + n)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if constexpr (GATHER) {
+            // row = pixel, 32 k-slots = 9 taps x Cin (3x3, pad 1, stride 1), zero padded
+            int row = tid >> 3, kq = (tid & 7) * 4;
+            int m = mbase + row;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (m < a.M) {
+                int b = m / HWl, rem = m - b * HWl, oh = rem / a.Wl, ow = rem - oh * a.Wl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int k = kq + e;
+                    if (k < 9 * a.Cin) {
+                        int t9 = k / a.Cin, c = k - t9 * a.Cin;
+                        int ih = oh + t9 / 3 - 1, iw = ow + t9 % 3 - 1;
+                        if ((unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win)
+                            v[e] = a.x[((size_t)(b * a.Hin + ih) * a.Win + iw) * a.Cin + c];
+                    }
+                }
+            }
+            rb[0] = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < BL; ++p) {
+                int f = tid + 256 * p, row = f / (TN / 4), col = (f % (TN / 4)) * 4;
+                int m = mbase + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < a.M) {
+                    int b = m / HWl, rem = m - b * HWl, oh = rem / a.Wl, ow = rem - oh * a.Wl;
+                    int ih = oh * a.is + dh, iw = ow * a.is + dw;
+                    if ((unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win)
+                        v = *reinterpret_cast<const float4*>(a.x + ((size_t)(b * a.Hin + ih) * a.Win + iw) * a.Cin + c0 + col);
+                }
+                rb[p] = v;
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < AL; ++p) {
+            int f = tid + 256 * p, row = f / (TM / 4), col = (f % (TM / 4)) * 4;
+            *reinterpret_cast<float4*>(&As[buf][row * LDA + col]) = ra[p];
+        }
+        if constexpr (GATHER) {
+            *reinterpret_cast<float4*>(&Bs[buf][(tid >> 3) * LDB + (tid & 7) * 4]) = rb[0];
+        } else {
+#pragma unroll
+            for (int p = 0; p < BL; ++p) {
+                int f = tid + 256 * p, row = f / (TN / 4), col = (f % (TN / 4)) * 4;
+                *reinterpret_cast<float4*>(&Bs[buf][row * LDB + col]) = rb[p];
+            }
+        }
+    };
+    auto compute = [&](const float* __restrict__ Asm, const float* __restrict__ Bsm) {
+        constexpr int KW = QUAD ? KP : KP / 4;  // pixels this wave consumes per chunk
+        const int kbase = QUAD ? 0 : wave * KW;
+#pragma unroll
+        for (int kk = 0; kk < KW; kk += 2) {
+            const int k = kbase + kk + (lane >> 5);
+            float af[MB], bf[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) af[i] = Asm[k * LDA + wm * WTM + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bf[j] = Bsm[k * LDB + wn * WTN + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    load(ch_begin);
+    stage(0);
+    __syncthreads();
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        const int cur = (ch - ch_begin) & 1;
+        const bool more = ch + 1 < ch_end;
+        if (more) load(ch + 1);
+        compute(As[cur], Bs[cur]);
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    const int half = lane >> 5, lc = lane & 31;
+    const int Kw = GATHER ? 9 * a.Cin : 0;
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int c = wn * WTN + j * 32 + lc;
+                if (n < a.N) {
+                    if constexpr (GATHER) {
+                        if (c < Kw) atomicAdd(a.dw + (size_t)n * Kw + c, acc[i][j][r]);
+                    } else {
+                        atomicAdd(a.dw + ((size_t)n * a.Tw + a.taps.wslot[tp]) * a.Cin + c0 + c, acc[i][j][r]);
+                    }
+                }
+            }
+}
+
+template <int TM, int TN, bool QUAD, bool GATHER>
+int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
+    const int ntap = GATHER ? 1 : a.taps.n;
+    const int tiles = ((a.N + TM - 1) / TM) * (GATHER ? 1 : a.Cin / TN) * ntap;
+    const int total_chunks = (a.M + KP - 1) / KP;
+    // enough K-splits to fill the chip ~4 blocks deep, but at least 8 chunks of work per block
+    int want = (256 * 8 + tiles - 1) / tiles;
+    int max_split = (total_chunks + 7) / 8;
+    int nsplit = want < 1 ? 1 : (want > max_split ? (max_split < 1 ? 1 : max_split) : want);
+    int cps = (total_chunks + nsplit - 1) / nsplit;
+    nsplit = (total_chunks + cps - 1) / cps;
+    hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER>), dim3(tiles, nsplit), dim3(256), 0, ctx->stream, a, cps, ntap);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+}  // namespace
+
+int fv_wgrad_launch(fv_ctx* ctx, const FvWgradArgs& a) {
+    FV_REQUIRE(ctx, a.x && a.dy && a.dw, "wgrad: NULL tensor");
+    FV_REQUIRE(ctx, a.M > 0 && a.N > 0 && a.Ndy >= a.N && a.Ndy % 4 == 0, "wgrad: bad sizes (Ndy must be a multiple of 4)");
+    FV_REQUIRE(ctx, (long long)a.B * a.Hin * a.Win * a.Cin < (1ll << 31) && (long long)a.M * a.Ndy < (1ll << 31),
+               "wgrad: tensor exceeds 2^31 elements");
+    if (a.Cin % 32 != 0) {
+        FV_REQUIRE(ctx, 9 * a.Cin <= 32 && a.is == 1 && a.Hl == a.Hin && a.Wl == a.Win && a.taps.n == 9,
+                   "wgrad: Cin=%d only supported as 3x3 stride-1 pad-1 with 9*Cin<=32", a.Cin);
+        if (a.N > 32) return launch_w<64, 32, false, true>(ctx, a);
+        return launch_w<32, 32, false, true>(ctx, a);
+    }
+    FV_REQUIRE(ctx, a.taps.n >= 1 && a.taps.n <= 9, "wgrad: bad tap count");
+    if (a.N >= 128 && a.Cin % 128 == 0) return launch_w<128, 128, true, false>(ctx, a);
+    const bool n64 = a.N > 32, c64 = a.Cin % 64 == 0;
+    if (n64 && c64) return launch_w<64, 64, false, false>(ctx, a);
+    if (n64) return launch_w<64, 32, false, false>(ctx, a);
+    if (c64) return launch_w<32, 64, false, false>(ctx, a);
+    return launch_w<32, 32, false, false>(ctx, a);
+}

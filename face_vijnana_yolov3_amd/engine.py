@@ -1,0 +1,153 @@
+"""Device engine behind FaceDetector: owns the flat parameter / optimiser / BN-state vectors
+(torch-ROCm tensors used as plain storage) and drives the C-ABI hot path.
+
+It plays the role of the compiled Keras `Model` in the reference (face_detection.py:341-382):
+`predict` (fd.py:899), one `fit_generator` step (fd.py:621-627), `save`/`load` (fd.py:630, 337)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import BUCKET_FN, Context, FvError, LayerDesc, lib, ptr, c_void_p
+
+HEAD_C = 6
+
+
+def layer_table():
+    """List of dicts mirroring fv_layer_desc (works without a GPU)."""
+    L = lib()
+    out = []
+    for i in range(L.fv_num_layers()):
+        d = LayerDesc()
+        assert L.fv_layer(i, ctypes.byref(d)) == 0
+        out.append({f: getattr(d, f) for f, _ in LayerDesc._fields_})
+    return out
+
+
+class Engine(object):
+    def __init__(self, device=0, stream=None):
+        self.ctx = Context(device, stream)
+        self.dev = torch.device('cuda', device)
+        self.layers = layer_table()
+        self.n_params = int(lib().fv_param_count())
+        self.n_state = int(lib().fv_state_count())
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.dev)
+        self.state = torch.zeros(self.n_state, dtype=torch.float32, device=self.dev)
+        self.grads = None
+        self.m = None
+        self.v = None
+        self.iterations = 0
+        self._ws = {}
+        self._loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self._bucket_cb = None
+
+    # ------------------------------------------------------------------ parameters
+    def set_params(self, params, state):
+        assert params.numel() == self.n_params and state.numel() == self.n_state
+        self.params.copy_(torch.as_tensor(params, dtype=torch.float32).reshape(-1))
+        self.state.copy_(torch.as_tensor(state, dtype=torch.float32).reshape(-1))
+
+    def init_synthetic(self, seed=7):
+        """Random-init weights of the SURVEY 8d config-2 shape (no pretrained file offline):
+        kernels ~ N(0, 2/fan_in), gamma 1, beta 0, moving mean 0 / var 1, head glorot-uniform."""
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        p = torch.zeros(self.n_params, dtype=torch.float32)
+        s = torch.zeros(self.n_state, dtype=torch.float32)
+        for d in self.layers:
+            k, cin, cout = d['ksize'], d['cin'], d['cout']
+            n = cout * k * k * cin
+            if d['has_bn']:
+                p[d['w_off']:d['w_off'] + n] = torch.randn(n, generator=g) * float(np.sqrt(2.0 / (k * k * cin)))
+                p[d['gamma_off']:d['gamma_off'] + cout] = 1.0
+                s[d['var_off']:d['var_off'] + cout] = 1.0
+            else:
+                lim = float(np.sqrt(6.0 / (k * k * cin + k * k * cout)))
+                p[d['w_off']:d['w_off'] + n] = (torch.rand(n, generator=g) * 2 - 1) * lim
+        self.set_params(p, s)
+
+    def _workspace(self, batch, image_size, training):
+        key = (batch, image_size, bool(training))
+        if key not in self._ws:
+            n = int(lib().fv_workspace_bytes(batch, image_size, 1 if training else 0))
+            if n == 0:
+                raise FvError('unsupported batch/image_size %r' % (key,))
+            self._ws = {k: v for k, v in self._ws.items() if k[2] != bool(training)}  # one per mode
+            self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.dev)
+        return self._ws[key]
+
+    def _as_input(self, x):
+        x = torch.as_tensor(x)
+        if x.dtype != torch.float32 or x.device != self.dev:
+            x = x.to(device=self.dev, dtype=torch.float32)
+        return x.contiguous()
+
+    # ------------------------------------------------------------------ predict (fd.py:899)
+    def predict_device(self, x):
+        """x: (B,S,S,3) float in [0,1] -> (B,S/32,S/32,6) float32 CUDA tensor (stream-ordered)."""
+        x = self._as_input(x)
+        B, S = x.shape[0], x.shape[1]
+        assert x.dim() == 4 and x.shape[2] == S and x.shape[3] == 3
+        ws = self._workspace(B, S, False)
+        y = torch.empty((B, S // 32, S // 32, HEAD_C), dtype=torch.float32, device=self.dev)
+        rc = lib().fv_forward_infer(self.ctx.handle, ptr(self.params), ptr(self.state), ptr(x), B, S, ptr(ws), ws.numel(), ptr(y))
+        self.ctx.check(rc, 'fv_forward_infer')
+        return y
+
+    def predict(self, x):
+        return self.predict_device(x).cpu().numpy()
+
+    # ------------------------------------------------------------------ training
+    def ensure_optimizer(self):
+        if self.grads is None:
+            self.grads = torch.zeros_like(self.params)
+            self.m = torch.zeros_like(self.params)
+            self.v = torch.zeros_like(self.params)
+
+    def forward_backward(self, x, y_true, on_bucket=None):
+        """fwd + mse + bwd; gradients land in self.grads; returns the loss as a 1-element CUDA
+        tensor (no host sync).  on_bucket(offset, count) is called as gradient ranges complete."""
+        self.ensure_optimizer()
+        x = self._as_input(x)
+        y_true = self._as_input(y_true)
+        B, S = x.shape[0], x.shape[1]
+        assert y_true.shape == (B, S // 32, S // 32, HEAD_C), y_true.shape
+        ws = self._workspace(B, S, True)
+        if on_bucket is not None:
+            cb = BUCKET_FN(lambda user, off, cnt: on_bucket(int(off), int(cnt)))
+        else:
+            cb = ctypes.cast(None, BUCKET_FN)
+        self._bucket_cb = cb  # keep alive during the call
+        rc = lib().fv_train_step(self.ctx.handle, ptr(self.params), ptr(self.state), ptr(x), ptr(y_true), B, S, ptr(ws),
+                                 ws.numel(), ptr(self.grads), ptr(self._loss), cb, None)
+        self.ctx.check(rc, 'fv_train_step')
+        return self._loss
+
+    def adam_step(self, lr, beta_1, beta_2, decay=0.0, eps=1e-7):
+        rc = lib().fv_adam_step(self.ctx.handle, ptr(self.params), ptr(self.grads), ptr(self.m), ptr(self.v), self.n_params,
+                                self.iterations, float(lr), float(beta_1), float(beta_2), float(eps), float(decay))
+        self.ctx.check(rc, 'fv_adam_step')
+        self.iterations += 1
+
+    def train_on_batch(self, x, y_true, lr, beta_1, beta_2, decay=0.0):
+        loss = self.forward_backward(x, y_true)
+        self.adam_step(lr, beta_1, beta_2, decay)
+        return loss
+
+    # ------------------------------------------------------------------ checkpoint (own format)
+    def save(self, path):
+        """Weights + BN moving stats + Adam state (the information Keras' model.save keeps,
+        fd.py:630).  Plain .npz; Keras-HDF5 interop is a SURVEY 8f 'next' row."""
+        d = dict(params=self.params.cpu().numpy(), state=self.state.cpu().numpy(), iterations=np.int64(self.iterations))
+        if self.m is not None:
+            d['m'] = self.m.cpu().numpy(); d['v'] = self.v.cpu().numpy()
+        with open(path, 'wb') as f:
+            np.savez(f, **d)
+
+    def load(self, path):
+        with open(path, 'rb') as f:
+            d = np.load(f)
+            self.set_params(torch.from_numpy(d['params']), torch.from_numpy(d['state']))
+            self.iterations = int(d['iterations'])
+            if 'm' in d:
+                self.ensure_optimizer()
+                self.m.copy_(torch.from_numpy(d['m'])); self.v.copy_(torch.from_numpy(d['v']))

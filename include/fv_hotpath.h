@@ -57,6 +57,102 @@ int fv_decode_nms(fv_ctx* ctx, const float* head, int nimg, int grid, int image_
                   double conf_th, double iou_th, int num_cands, int32_t* boxes, int32_t* cell,
                   float* obj, float* score, int32_t* count);
 
+
+/* ------------------------------------------------------------------ network description
+ * The FaceDetector network: the first 52 conv+BN+LeakyReLU(0.1) layers / 23 residual adds of
+ * make_yolov3_model (yd.py:221-267) as re-wired by FaceDetector.YOLOV3Base (fd.py:404-593), plus
+ * the Conv2D(6, 3x3, 'same', linear, bias) head (fd.py:348-352).  Parameters live in ONE flat
+ * float32 vector owned by the caller (so Adam and the gradient all-reduce are single ranges):
+ *   per base layer: kernel OHWI [cout][k][k][cin] at w_off, gamma[cout] at gamma_off, beta[cout]
+ *   at beta_off;  head: kernel at w_off, bias[6] at beta_off (gamma_off = -1).
+ * BatchNorm moving statistics live in a second flat vector: mean at mean_off, var at var_off. */
+typedef struct fv_layer_desc {
+    int32_t darknet_index; /* conv_<i> / bnorm_<i> of yd.py; -1 for the head ('output') */
+    int32_t ksize, stride, cin, cout;
+    int32_t has_bn;        /* 1: BN(eps 1e-3)+LeakyReLU(0.1) follow; 0: linear + bias (head) */
+    int32_t role;          /* 0 plain, 1 first conv of a residual block (its input is the skip),
+                              2 second conv of a residual block (add(skip, x) follows), 3 head */
+    int32_t in_div, out_div; /* spatial size = image_size / div */
+    int64_t w_off, gamma_off, beta_off; /* offsets (floats) into the parameter vector */
+    int64_t mean_off, var_off;          /* offsets into the BN-state vector (-1 for the head) */
+} fv_layer_desc;
+
+int fv_num_layers(void);                       /* 53 */
+int fv_layer(int i, fv_layer_desc* out);
+int64_t fv_param_count(void);                  /* 40 640 230 trainable floats */
+int64_t fv_state_count(void);                  /* 35 712 BN moving mean/var floats */
+/* bytes of caller-provided device workspace for a batch; training != 0 keeps every layer's
+ * pre-BN and activated output for the backward pass. */
+size_t fv_workspace_bytes(int batch, int image_size, int training);
+
+/* ------------------------------------------------------------------ hot path: network level */
+/* Replaces self.model.predict(image) (fd.py:899): BN in inference mode (moving statistics folded
+ * into the conv epilogue), x [batch][S][S][3] float32 NHWC in [0,1], y [batch][S/32][S/32][6]. */
+int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, const float* x, int batch,
+                     int image_size, void* workspace, size_t workspace_bytes, float* y);
+
+/* Called (on the host, in enqueue order) when the gradient range [offset, offset+count) of the
+ * flat gradient vector has been fully enqueued on the context's stream -- the hook a data-parallel
+ * host uses to start the RCCL all-reduce of that bucket while the backward pass continues. */
+typedef void (*fv_bucket_fn)(void* user, int64_t offset, int64_t count);
+
+/* One optimisation step's forward + loss + backward; replaces the TF graph that
+ * model.fit_generator runs per batch (fd.py:621-627) with loss='mse' (fd.py:381): training-mode BN
+ * (batch statistics, moving statistics updated in bn_state), mean-squared error over every element
+ * of [batch][G][G][6], gradients of all 40 640 230 parameters written to `grads` (overwritten).
+ * loss: one float (device).  Follow with fv_adam_step. */
+int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float* x, const float* y_true,
+                  int batch, int image_size, void* workspace, size_t workspace_bytes, float* grads,
+                  float* loss, fv_bucket_fn on_bucket, void* user);
+
+/* keras.optimizers.Adam(lr, beta_1, beta_2, decay) update (fd.py:376-379), Keras 2.2.4 formula:
+ * t = iteration+1; lr_t = lr/(1+decay*iteration) * sqrt(1-b2^t)/(1-b1^t);
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m / (sqrt(v) + eps)  (eps = 1e-7). */
+int fv_adam_step(fv_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n,
+                 int64_t iteration, double lr, double beta_1, double beta_2, double eps, double decay);
+
+/* ------------------------------------------------------------------ hot path: single operators
+ * (what the network-level calls are built from; exported for unit parity tests) */
+/* ZeroPadding2D(1)+Conv2D(k=3,'valid',strides=stride) or Conv2D(k=1) of yd.py:205-211.
+ * x [B][H][W][cin], w OHWI [cout][k][k][cin] (cin % 32 == 0; for the cin=3 first layer pass the
+ * [cout][32] form made by fv_pack_first_layer), out [B][H/stride][W/stride][cout].
+ * out = acc*scale[c]+shift[c] (either may be NULL), then LeakyReLU(leaky) if leaky >= 0, then
+ * + addend (may be NULL).  If psum != NULL the raw result is stored instead and psum/psq receive
+ * per-tile column sums / sums of squares, [fv_conv2d_stat_rows(M)][cout] each. */
+int fv_conv2d_forward(fv_ctx* ctx, const float* x, const float* w, int B, int H, int W, int cin, int cout,
+                      int ksize, int stride, const float* scale, const float* shift, float leaky,
+                      const float* addend, float* out, float* psum, float* psq);
+int fv_conv2d_stat_rows(int64_t out_pixels);
+/* gradient w.r.t. the conv input.  dy [B][H/stride][W/stride][cout_pad], w_t [cin][k*k][cout_pad]
+ * (fv_transpose_weights), dx [B][H][W][cin] = dgrad (+ addend if not NULL). */
+int fv_conv2d_dgrad(fv_ctx* ctx, const float* dy, const float* w_t, int B, int H, int W, int cin,
+                    int cout_pad, int ksize, int stride, const float* addend, float* dx);
+/* gradient w.r.t. the kernel, ACCUMULATED into dw OHWI [cout][k][k][cin] (zero it first).
+ * dy has dy_stride >= cout channels per pixel. */
+int fv_conv2d_wgrad(fv_ctx* ctx, const float* x, const float* dy, int B, int H, int W, int cin, int cout,
+                    int dy_stride, int ksize, int stride, float* dw);
+int fv_transpose_weights(fv_ctx* ctx, const float* w, int cout, int taps, int cin, int cout_pad, float* w_t);
+int fv_pack_first_layer(fv_ctx* ctx, const float* w, int cout, int k_elems, float* w_packed /*[cout][32]*/);
+/* training-mode BatchNormalization(eps) statistics from the conv partials: mean, 1/sqrt(var+eps),
+ * scale = gamma*invstd, shift = beta-mean*scale; moving stats updated in place when not NULL
+ * (Keras: moving = momentum*moving + (1-momentum)*batch, variance scaled by n/(n-(1+eps))). */
+int fv_bn_finalize(fv_ctx* ctx, const float* psum, const float* psq, int stat_rows, int C, int64_t count,
+                   const float* gamma, const float* beta, float eps, float momentum, float* mean,
+                   float* invstd, float* scale, float* shift, float* moving_mean, float* moving_var);
+/* out = LeakyReLU(z*scale+shift) (+ skip) over [rows][C] */
+int fv_bn_act(fv_ctx* ctx, const float* z, const float* scale, const float* shift, const float* skip,
+              float* out, int64_t rows, int C, float leaky);
+/* backward of BN(train)+LeakyReLU: dz, dgamma[C], dbeta[C] from g = dL/d(activated output).
+ * scratch: 2 * fv_bn_bwd_scratch_floats(rows, C) floats. */
+int64_t fv_bn_bwd_scratch_floats(int64_t rows, int C);
+int fv_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale, const float* shift,
+              const float* mean, const float* invstd, int64_t rows, int C, float leaky, float* scratch,
+              float* dbeta, float* dgamma, float* dz);
+/* loss = mean((yp-yt)^2) over [rows][C]; dy [rows][c_pad] = 2(yp-yt)/(rows*C) zero padded;
+ * dbias[C] = column sums of dy (may be NULL). */
+int fv_mse_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int c_pad,
+                     float* loss, float* dy, float* dbias);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,128 @@
+"""Network-level GPU parity (through fv_forward_infer / fv_train_step / fv_adam_step) against the
+torch-CPU oracle on identical weights and inputs.
+
+Tolerance policy: the kernels are exact fp32; the yardstick is the oracle evaluated in float64.
+We require the GPU error against float64 to be within 4x of the error the SAME oracle makes when
+run in float32 on the CPU (plus a small absolute floor) -- i.e. "as accurate as an fp32 CPU
+reference", which is what the reference's Keras/TF CPU path is."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from face_vijnana_yolov3_amd.engine import Engine
+    return Engine(0)
+
+
+def _within(got, ref64, ref32, what, factor=4.0, floor=1e-6):
+    e_gpu = (got.double() - ref64).abs()
+    e_cpu = (ref32.double() - ref64).abs()
+    scale = ref64.abs().max().item()
+    lim = factor * e_cpu.max().item() + floor * max(scale, 1.0)
+    assert e_gpu.max().item() <= lim, '%s: gpu err %.3e > limit %.3e (cpu fp32 err %.3e, scale %.3e)' % (
+        what, e_gpu.max().item(), lim, e_cpu.max().item(), scale)
+
+
+def test_layer_table_matches_oracle(eng):
+    from oracle import net_oracle as no
+    ents, n, ns = no.param_layout()
+    assert eng.n_params == n and eng.n_state == ns and len(eng.layers) == len(ents)
+    role = {'plain': 0, 'res_a': 1, 'res_b': 2, 'head': 3}
+    for d, e in zip(eng.layers, ents):
+        assert (d['darknet_index'], d['ksize'], d['stride'], d['cin'], d['cout']) == (e['idx'], e['k'], e['s'], e['cin'], e['cout'])
+        assert d['role'] == role[e['role']] and d['w_off'] == e['w_off']
+        if e['has_bn']:
+            assert (d['gamma_off'], d['beta_off'], d['mean_off'], d['var_off']) == (e['gamma_off'], e['beta_off'], e['mean_off'], e['var_off'])
+        else:
+            assert d['beta_off'] == e['bias_off']
+
+
+def _setup(seed, B, S):
+    from oracle import net_oracle as no
+    p64, s64 = no.init_params(seed, torch.float64)
+    g = torch.Generator().manual_seed(seed + 100)
+    # non-trivial BN parameters / moving stats so every term is exercised
+    ents, _, _ = no.param_layout()
+    for e in ents:
+        if e['has_bn']:
+            c = e['cout']
+            p64[e['gamma_off']:e['gamma_off'] + c] = 0.8 + 0.4 * torch.rand(c, generator=g, dtype=torch.float64)
+            p64[e['beta_off']:e['beta_off'] + c] = 0.2 * torch.randn(c, generator=g, dtype=torch.float64)
+            s64[e['mean_off']:e['mean_off'] + c] = 0.1 * torch.randn(c, generator=g, dtype=torch.float64)
+            s64[e['var_off']:e['var_off'] + c] = 0.5 + torch.rand(c, generator=g, dtype=torch.float64)
+        else:
+            p64[e['bias_off']:e['bias_off'] + 6] = 0.1 * torch.randn(6, generator=g, dtype=torch.float64)
+    x = torch.rand((B, S, S, 3), generator=g, dtype=torch.float64)
+    yt = torch.rand((B, S // 32, S // 32, 6), generator=g, dtype=torch.float64)
+    return p64, s64, x, yt
+
+
+@pytest.mark.parametrize('B,S', [(1, 96), (3, 64)])
+def test_forward_infer_matches_oracle(eng, B, S):
+    from oracle import net_oracle as no
+    p64, s64, x, _ = _setup(5, B, S)
+    y64, _ = no.forward(p64, s64, x, training=False)
+    y32, _ = no.forward(p64.float(), s64.float(), x.float(), training=False)
+    eng.set_params(p64.float(), s64.float())
+    y = eng.predict_device(x.float())
+    torch.cuda.synchronize()
+    _within(y.cpu(), y64, y32, 'forward_infer')
+
+
+def test_train_step_matches_oracle(eng):
+    from oracle import net_oracle as no
+    B, S = 4, 96
+    p64, s64, x, yt = _setup(9, B, S)
+    l64, g64, ns64 = no.train_step_grads(p64, s64, x, yt)
+    l32, g32, ns32 = no.train_step_grads(p64.float(), s64.float(), x.float(), yt.float())
+    eng.set_params(p64.float(), s64.float())
+    eng.iterations = 0
+    eng.m = eng.v = eng.grads = None
+    buckets = []
+    loss = eng.forward_backward(x.float(), yt.float(), on_bucket=lambda off, cnt: buckets.append((off, cnt)))
+    torch.cuda.synchronize()
+    assert abs(loss.item() - l64.item()) <= 4 * abs(l32.item() - l64.item()) + 1e-6 * abs(l64.item())
+    _within(eng.state.cpu(), ns64, ns32, 'bn moving state')
+    # gradients: per-layer comparison (scales differ by orders of magnitude between layers)
+    ents, n, _ = no.param_layout()
+    g = eng.grads.cpu()
+    for e in ents:
+        k, cin, cout = e['k'], e['cin'], e['cout']
+        sl = slice(e['w_off'], e['w_off'] + cout * k * k * cin)
+        _within(g[sl], g64[sl], g32[sl], 'dW ' + e['name'], factor=6.0, floor=2e-6)
+        if e['has_bn']:
+            for nm in ('gamma_off', 'beta_off'):
+                sl = slice(e[nm], e[nm] + cout)
+                _within(g[sl], g64[sl], g32[sl], nm + ' ' + e['name'], factor=6.0, floor=2e-6)
+        else:
+            sl = slice(e['bias_off'], e['bias_off'] + 6)
+            _within(g[sl], g64[sl], g32[sl], 'dbias', factor=6.0, floor=2e-6)
+    # buckets: reverse layer order, disjoint, cover every parameter exactly once
+    assert buckets[0][0] == ents[-1]['w_off']
+    assert sorted(buckets) == sorted(buckets, key=lambda b: b[0]) and [b[0] for b in buckets] == sorted([b[0] for b in buckets], reverse=True)
+    assert sum(c for _, c in buckets) == n
+    ends = sorted((o, o + c) for o, c in buckets)
+    assert ends[0][0] == 0 and all(ends[i][1] == ends[i + 1][0] for i in range(len(ends) - 1)) and ends[-1][1] == n
+    # Adam (Keras formula) on top of the gradients, two steps
+    rp, rm, rv = p64.clone(), torch.zeros_like(p64), torch.zeros_like(p64)
+    gg = g.double()
+    for it in range(2):
+        eng.adam_step(1e-4, 0.99, 0.99)
+        rp, rm, rv = no.keras_adam(rp, gg, rm, rv, it, 1e-4, 0.99, 0.99)
+    torch.testing.assert_close(eng.params.cpu().double(), rp, rtol=1e-6, atol=2e-7)
+    assert eng.iterations == 2
+
+
+def test_workspace_too_small_is_reported(eng):
+    import ctypes
+    from face_vijnana_yolov3_amd._lib import lib, ptr
+    x = torch.zeros((1, 64, 64, 3), device='cuda'); y = torch.zeros((1, 2, 2, 6), device='cuda')
+    ws = torch.empty(1024, dtype=torch.uint8, device='cuda')
+    rc = lib().fv_forward_infer(eng.ctx.handle, ptr(eng.params), ptr(eng.state), ptr(x), 1, 64, ptr(ws), ws.numel(), ptr(y))
+    assert rc == -3 and b'workspace' in lib().fv_last_error(eng.ctx.handle)
+    rc = lib().fv_forward_infer(eng.ctx.handle, ptr(eng.params), ptr(eng.state), ptr(x), 1, 70, ptr(ws), ws.numel(), ptr(y))
+    assert rc == -1
