@@ -17,6 +17,9 @@ def lib():
     """Load libfv_hotpath.so; raise loudly when it has not been built."""
     global _lib
     if _lib is None:
+        # torch bundles its own HIP runtime (libamdhip64): import it FIRST so this library binds to
+        # the same runtime instance -- device pointers, streams and events are shared with torch.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise FvError('libfv_hotpath.so not built: run `python -m face_vijnana_yolov3_amd.build` '
                           '(there is no CPU fallback for the hot path)')
@@ -47,12 +50,19 @@ class LayerDesc(ctypes.Structure):
                 ('mean_off', ctypes.c_int64), ('var_off', ctypes.c_int64)]
 
 
+class ProfileRec(ctypes.Structure):
+    _fields_ = [('name', ctypes.c_char * 64), ('launches', ctypes.c_int64), ('ms_total', ctypes.c_double),
+                ('flops_total', ctypes.c_double), ('bytes_total', ctypes.c_double)]
+
+
 BUCKET_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64)
 
 
 def _declare(L):
     i32, i64, f32, f64, vp, sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, c_void_p, ctypes.c_size_t
     sig = {
+        'fv_profile_enable': (i32, [vp, i32]),
+        'fv_profile_collect': (i32, [vp, ctypes.POINTER(ProfileRec), i32, ctypes.POINTER(i32)]),
         'fv_num_layers': (i32, []),
         'fv_layer': (i32, [i32, ctypes.POINTER(LayerDesc)]),
         'fv_param_count': (i64, []),
@@ -105,6 +115,18 @@ class Context:
 
     def set_stream(self, stream_ptr):
         self.check(lib().fv_set_stream(self._h, c_void_p(stream_ptr)), 'fv_set_stream')
+
+    def profile(self, on):
+        self.check(lib().fv_profile_enable(self._h, 1 if on else 0), 'fv_profile_enable')
+
+    def profile_collect(self):
+        """-> {kernel name: dict(launches, ms, flops, bytes)} since profiling was enabled (syncs)."""
+        recs = (ProfileRec * 64)()
+        n = ctypes.c_int(0)
+        self.check(lib().fv_profile_collect(self._h, recs, 64, ctypes.byref(n)), 'fv_profile_collect')
+        return {recs[i].name.decode(): dict(launches=int(recs[i].launches), ms=recs[i].ms_total,
+                                            flops=recs[i].flops_total, bytes=recs[i].bytes_total)
+                for i in range(min(n.value, 64))}
 
     def close(self):
         if self._h:

@@ -14,9 +14,62 @@ int fv_fail(fv_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
+fv_ctx::~fv_ctx() {
+    for (auto& r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : ev_pool) (void)hipEventDestroy(e);
+}
+
+static hipEvent_t take_event(fv_ctx* c) {
+    hipEvent_t e = nullptr;
+    if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+FvProfScope::FvProfScope(fv_ctx* c, const char* name, double flops, double bytes) : ctx(c) {
+    if (!c || !c->prof_on) return;
+    hipEvent_t e0 = take_event(c);
+    e1 = take_event(c);
+    if (!e0 || !e1) { e1 = nullptr; return; }
+    (void)hipEventRecord(e0, c->stream);
+    c->prof.push_back(FvProfRec{name, flops, bytes, e0, e1});
+}
+FvProfScope::~FvProfScope() {
+    if (e1) (void)hipEventRecord(e1, ctx->stream);
+}
+
 extern "C" {
 
 int fv_abi_version(void) { return 1; }
+
+int fv_profile_enable(fv_ctx* ctx, int on) {
+    if (!ctx) return FV_ERR_INVALID;
+    ctx->prof_on = on != 0;
+    return FV_OK;
+}
+
+int fv_profile_collect(fv_ctx* ctx, fv_profile_rec* out, int max_recs, int* n_out) {
+    if (!ctx || !n_out) return FV_ERR_INVALID;
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<fv_profile_rec> agg;
+    for (auto& r : ctx->prof) {
+        float ms = 0.f;
+        FV_HIP(ctx, hipEventElapsedTime(&ms, r.e0, r.e1));
+        size_t k = 0;
+        for (; k < agg.size(); ++k) if (std::string(agg[k].name) == r.name) break;
+        if (k == agg.size()) {
+            fv_profile_rec a{};
+            snprintf(a.name, sizeof a.name, "%s", r.name);
+            agg.push_back(a);
+        }
+        agg[k].launches += 1; agg[k].ms_total += ms; agg[k].flops_total += r.flops; agg[k].bytes_total += r.bytes;
+        ctx->ev_pool.push_back(r.e0); ctx->ev_pool.push_back(r.e1);
+    }
+    ctx->prof.clear();
+    *n_out = (int)agg.size();
+    for (int i = 0; i < (int)agg.size() && i < max_recs; ++i) out[i] = agg[i];
+    return FV_OK;
+}
 
 int fv_create(int device, void* stream, fv_ctx** out) {
     if (!out) return fv_fail(nullptr, FV_ERR_INVALID, "fv_create: out is NULL");

@@ -3,12 +3,32 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <string>
+#include <vector>
 #include "../../include/fv_hotpath.h"
+
+struct FvProfRec {
+    const char* name;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
 
 struct fv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    // optional per-launch timing (fv_profile_enable): HIP event pairs on the launch stream
+    bool prof_on = false;
+    std::vector<FvProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+    ~fv_ctx();
+};
+
+// RAII: brackets one kernel launch with HIP events when profiling is enabled.
+struct FvProfScope {
+    fv_ctx* ctx;
+    hipEvent_t e1 = nullptr;
+    FvProfScope(fv_ctx* c, const char* name, double flops, double bytes);
+    ~FvProfScope();
 };
 
 int fv_fail(fv_ctx* ctx, int code, const char* fmt, ...);

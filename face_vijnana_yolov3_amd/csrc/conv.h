@@ -35,6 +35,7 @@ struct FvConvArgs {
     int epi;
     float leaky;
     int nclass;   // 1, or 4 for stride-2 data-gradient
+    double alg_flops;  // algorithmic 2*MAC of this launch (profiling only)
     int oph[4], opw[4];
     FvTaps taps[4];
 };
@@ -56,6 +57,7 @@ struct FvWgradArgs {
     int is;
     int Tw;                // taps per output channel in dw
     int M;                 // B*Hl*Wl
+    double alg_flops;      // algorithmic 2*MAC of this launch (profiling only)
     FvTaps taps;
 };
 int fv_wgrad_launch(fv_ctx* ctx, const FvWgradArgs& a);

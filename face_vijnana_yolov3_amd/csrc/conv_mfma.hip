@@ -252,6 +252,12 @@ template <int BN, int WM_, int WN_, bool G>
 int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
     const int MT = (a.M + BM - 1) / BM, NT = (a.Nout + BN - 1) / BN;
     dim3 grid(MT * NT, 1, a.nclass);
+    static const char* name = BN == 128 ? (G ? "conv_kernel<128,2,2,true>" : "conv_kernel<128,2,2,false>")
+                              : BN == 64 ? (G ? "conv_kernel<64,2,2,true>" : "conv_kernel<64,2,2,false>")
+                                         : (G ? "conv_kernel<32,4,1,true>" : "conv_kernel<32,4,1,false>");
+    FvProfScope ps(ctx, name, a.alg_flops,
+                   4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.Nout * a.Tw * a.Cin +
+                          (double)a.M * a.nclass * a.Nout * ((a.epi & FV_EPI_ADD) ? 2 : 1)));
     hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G>), grid, dim3(256), 0, ctx->stream, a);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;

@@ -252,6 +252,7 @@ inline int grid_for(long long n, int block, int cap = 256 * 8) {
 int fv_ew_bn_finalize(fv_ctx* ctx, const float* psum, const float* psq, int mtiles, int C, double count, const float* gamma,
                       const float* beta, float eps, float momentum, float* mean, float* invstd, float* scale, float* shift,
                       float* moving_mean, float* moving_var) {
+    FvProfScope ps(ctx, "bn_finalize_kernel", 0.0, 8.0 * mtiles * C);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, ctx->stream, psum, psq, mtiles, C, count, gamma,
                        beta, eps, momentum, mean, invstd, scale, shift, moving_mean, moving_var);
     FV_LAUNCH_CHECK(ctx);
@@ -269,6 +270,7 @@ int fv_ew_bn_act(fv_ctx* ctx, const float* z, const float* scale, const float* s
                  long long rows, int C, float leaky) {
     FV_REQUIRE(ctx, C % 4 == 0, "bn_act: C must be a multiple of 4");
     long long n4 = rows * C / 4;
+    FvProfScope ps(ctx, "bn_act_kernel", 0.0, 4.0 * rows * C * (skip ? 3 : 2));
     hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, ctx->stream, (const float4*)z, scale, shift,
                        (const float4*)skip, (float4*)out, n4, C, leaky);
     FV_LAUNCH_CHECK(ctx);
@@ -289,12 +291,16 @@ int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale
     long long rpb = (rows + 2047) / 2048;
     if (rpb < 64) rpb = 64;
     int chunks = (int)((rows + rpb - 1) / rpb);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(chunks), dim3(256), 0, ctx->stream, g, z, scale, shift, mean, invstd, rows, C,
-                       (int)rpb, leaky, pdb, pdg);
+    {
+        FvProfScope ps(ctx, "bn_bwd_reduce_kernel", 0.0, 8.0 * rows * C);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(chunks), dim3(256), 0, ctx->stream, g, z, scale, shift, mean, invstd, rows, C,
+                           (int)rpb, leaky, pdb, pdg);
+    }
     FV_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, ctx->stream, pdb, pdg, chunks, C, dbeta, dgamma);
     FV_LAUNCH_CHECK(ctx);
     long long n4 = rows * C / 4;
+    FvProfScope ps(ctx, "bn_bwd_apply_kernel", 0.0, 12.0 * rows * C);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, ctx->stream, (const float4*)g, (const float4*)z,
                        scale, shift, mean, invstd, dbeta, dgamma, (float)(1.0 / (double)rows), n4, C, leaky, (float4*)dz);
     FV_LAUNCH_CHECK(ctx);
@@ -311,6 +317,7 @@ int fv_ew_mse(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, in
 
 int fv_ew_adam(fv_ctx* ctx, float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2, float eps) {
     long long n4 = n / 4;
+    FvProfScope ps(ctx, "adam_kernel", 0.0, 28.0 * n);
     if (n4 > 0) {
         hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4, 256, 256 * 16)), dim3(256), 0, ctx->stream, (float4*)p, (const float4*)g,
                            (float4*)m, (float4*)v, n4, lr_t, b1, b2, eps);
@@ -324,6 +331,7 @@ int fv_ew_adam(fv_ctx* ctx, float* p, const float* g, float* m, float* v, long l
 }
 
 int fv_ew_transpose_ntc(fv_ctx* ctx, const float* src, float* dst, int N, int T, int C, int Npad) {
+    FvProfScope ps(ctx, "transpose_ntc_kernel", 0.0, 4.0 * T * C * ((double)N + Npad));
     hipLaunchKernelGGL(transpose_ntc_kernel, dim3((C + 31) / 32, (Npad + 31) / 32, T), dim3(256), 0, ctx->stream, src, dst, N, T, C, Npad);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;

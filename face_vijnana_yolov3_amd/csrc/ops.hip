@@ -24,6 +24,7 @@ int fv_op_conv_forward(fv_ctx* ctx, const float* x, const float* w, int B, int H
     a.epi = epi; a.leaky = leaky; a.nclass = 1;
     fwd_taps(ksize, a.taps[0]);
     if (cin % 32 != 0) a.Tw = 1;  // packed [cout][32] first-layer weights
+    a.alg_flops = 2.0 * a.M * cout * (double)(ksize * ksize * cin);
     return fv_conv_launch(ctx, a);
 }
 
@@ -69,6 +70,8 @@ int fv_op_conv_dgrad(fv_ctx* ctx, const float* dy, const float* w_t, int B, int 
             }
     }
     a.M = B * a.Hl * a.Wl;
+    // same MACs as the forward conv it differentiates (cout_real unknown here: padded channels are zeros)
+    a.alg_flops = 2.0 * (double)B * (H / stride) * (W / stride) * cin * (double)(ksize * ksize * cout_pad);
     return fv_conv_launch(ctx, a);
 }
 
@@ -81,6 +84,7 @@ int fv_op_conv_wgrad(fv_ctx* ctx, const float* x, const float* dy, int B, int H,
     a.Hl = H / stride; a.Wl = W / stride; a.N = cout; a.Ndy = dy_stride;
     a.is = stride; a.Tw = ksize * ksize; a.M = B * a.Hl * a.Wl;
     fwd_taps(ksize, a.taps);
+    a.alg_flops = 2.0 * a.M * cout * (double)(ksize * ksize * cin);
     return fv_wgrad_launch(ctx, a);
 }
 

@@ -197,6 +197,7 @@ extern "C" int fv_decode_nms(fv_ctx* ctx, const float* head, int nimg, int grid,
     FV_REQUIRE(ctx, num_cands >= 1 && num_cands <= 512, "fv_decode_nms: num_cands %d unsupported (1..512)", num_cands);
     FV_REQUIRE(ctx, ((uintptr_t)boxes & 15) == 0, "fv_decode_nms: boxes must be 16-byte aligned");
     const int ncell = grid * grid;
+    FvProfScope ps(ctx, "decode_nms_kernel", 0.0, (double)nimg * (ncell * 24.0 + num_cands * 28.0 + 4.0));
     if (ncell <= 256 && num_cands <= 256)
         hipLaunchKernelGGL(decode_nms_kernel<256>, dim3(nimg), dim3(256), 0, ctx->stream, head, grid, image_size,
                            conf_th, iou_th, num_cands, boxes, cell, obj, score, count);

@@ -176,6 +176,12 @@ int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
     int nsplit = want < 1 ? 1 : (want > max_split ? (max_split < 1 ? 1 : max_split) : want);
     int cps = (total_chunks + nsplit - 1) / nsplit;
     nsplit = (total_chunks + cps - 1) / cps;
+    static const char* name = QUAD ? "wgrad_kernel<128,128,quad>"
+                              : GATHER ? (TM == 64 ? "wgrad_kernel<64,32,gather>" : "wgrad_kernel<32,32,gather>")
+                              : TM == 64 ? (TN == 64 ? "wgrad_kernel<64,64>" : "wgrad_kernel<64,32>")
+                                         : (TN == 64 ? "wgrad_kernel<32,64>" : "wgrad_kernel<32,32>");
+    FvProfScope ps(ctx, name, a.alg_flops,
+                   4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.M * a.N + (double)a.N * a.Tw * a.Cin));
     hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER>), dim3(tiles, nsplit), dim3(256), 0, ctx->stream, a, cps, ntap);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;

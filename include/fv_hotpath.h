@@ -43,6 +43,19 @@ void fv_destroy(fv_ctx* ctx);
 const char* fv_last_error(const fv_ctx* ctx);
 int fv_set_stream(fv_ctx* ctx, void* stream);
 
+/* ------------------------------------------------------------------ per-kernel timing
+ * Measurement aid with no counterpart in the reference (it has no profiler hooks):
+ * when enabled, every kernel launch of this library is bracketed by a HIP event pair on the
+ * context's stream; fv_profile_collect synchronises and returns one aggregate per kernel with
+ * the ALGORITHMIC flops / bytes of the launches (what bench.py's `roofline` is computed from). */
+typedef struct fv_profile_rec {
+    char name[64];
+    int64_t launches;
+    double ms_total, flops_total, bytes_total;
+} fv_profile_rec;
+int fv_profile_enable(fv_ctx* ctx, int on);
+int fv_profile_collect(fv_ctx* ctx, fv_profile_rec* out, int max_recs, int* n_out);
+
 /* ------------------------------------------------------------------ detect post-processing
  * Replaces the NumPy/Python tail of FaceDetector.detect (fd.py:900-947): float32 sigmoid,
  * threshold, per-cell box decode, do_nms_v2 (yd.py:446-458, IoU yd.py:165-194), score>0
