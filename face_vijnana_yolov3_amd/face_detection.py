@@ -1,0 +1,278 @@
+"""FaceDetector: drop-in for the train / evaluate / test / detect surface of the reference's
+`src/space/face_detection.py` (class FaceDetector fd.py:66-949, main() fd.py:951-985), running the
+network and the detect post-processing on MI355X through the C ABI.
+
+Same constructor (`conf = json['fd_conf']`), same methods, same config keys, same side-effect
+files (solution csv with 6 columns and no header, <test_path>/results/*_detected.jpg,
+ratios.csv, the model files).  Differences, all documented in DESIGN.md:
+  * model files are .npz written by Engine.save (no HDF5 library offline); names are kept
+  * the grid is image_size/32 (the reference hard-codes 13, consistent only at 416)
+  * multi_gpu=True means one process per GPU (torchrun) with RCCL all-reduce instead of
+    keras.utils.multi_gpu_model towers; launched as a single process it trains on one GPU
+  * evaluate() tolerates images without ground-truth rows and a missing arial.ttf
+"""
+import glob
+import json
+import os
+import platform
+import shutil
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import data
+from .postproc import BoundBox, decode_nms, to_boundboxes
+
+DEBUG = True
+
+
+class FaceDetector(object):
+    """Face detector using the Darknet-53 base of YOLOv3."""
+
+    MODEL_PATH = 'face_detector.h5'
+    BASE_MODEL_PATH = 'yolov3_base.h5'
+    DARKNET_WEIGHTS_PATH = 'yolov3.weights'
+    OUTPUT_FILE_NAME = 'solution.csv'
+    EVALUATION_FILE_NAME = 'eval.csv'
+    CELL_SIZE = 13
+
+    TrainingSequence = data.TrainingSequence
+
+    def __init__(self, conf, device=None):
+        from .engine import Engine
+        self.conf = conf
+        self.raw_data_path = conf['raw_data_path']
+        self.hps = conf['hps']
+        self.nn_arch = conf['nn_arch']
+        self.model_loading = conf['model_loading']
+        self.image_size = int(self.nn_arch['image_size'])
+        if self.image_size % 32:
+            raise ValueError('image_size must be a multiple of 32 (network stride)')
+        if int(self.nn_arch.get('bb_info_c_size', 6)) != 6:
+            raise ValueError('bb_info_c_size must be 6')
+        self.grid = self.image_size // 32
+        self.cell_image_size = self.image_size // self.grid
+        self.rank = int(os.environ.get('RANK', 0))
+        self.world = int(os.environ.get('WORLD_SIZE', 1)) if conf.get('multi_gpu') else 1
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', 0))
+        self.model = Engine(device)
+        if self.model_loading:
+            self.model.load(self.MODEL_PATH)
+        else:
+            self._load_base()
+            self._init_head()
+
+    # ------------------------------------------------------------------ model construction
+    def _load_base(self):
+        """YOLOV3Base (fd.py:384-600): cached base file, else Darknet weights, else -- because
+        neither can be downloaded offline -- synthetic initialisation (announced)."""
+        from . import weights
+        eng = self.model
+        if self.conf.get('yolov3_base_model_load') and os.path.exists(self.BASE_MODEL_PATH):
+            eng.load(self.BASE_MODEL_PATH)
+        elif os.path.exists(self.DARKNET_WEIGHTS_PATH):
+            p, s = weights.read_darknet_base(self.DARKNET_WEIGHTS_PATH, eng.layers, eng.n_params, eng.n_state)
+            eng.set_params(p, s)
+            if self.rank == 0:
+                eng.save(self.BASE_MODEL_PATH)
+        else:
+            print('FaceDetector: neither %s nor %s found; using synthetic base weights'
+                  % (self.BASE_MODEL_PATH, self.DARKNET_WEIGHTS_PATH))
+            eng.init_synthetic(seed=7)
+
+    def _init_head(self, seed=None):
+        """Keras default for the 'output' Conv2D: glorot_uniform kernel, zero bias (fd.py:348-352)."""
+        import torch
+        eng = self.model
+        d = eng.layers[-1]
+        n = d['cout'] * 9 * d['cin']
+        lim = float(np.sqrt(6.0 / (9 * d['cin'] + 9 * d['cout'])))
+        g = torch.Generator().manual_seed(0 if seed is None else seed)
+        eng.params[d['w_off']:d['w_off'] + n] = ((torch.rand(n, generator=g) * 2 - 1) * lim).to(eng.dev)
+        eng.params[d['beta_off']:d['beta_off'] + d['cout']] = 0
+
+    # ------------------------------------------------------------------ train (fd.py:602-630)
+    def train(self):
+        import torch
+        from .parallel import DataParallelTrainer
+        seq = self.TrainingSequence(self.raw_data_path, self.hps, self.nn_arch, self.grid, self.cell_image_size)
+        trainer = DataParallelTrainer(self.model, world_size=self.world, rank=self.rank)
+        hp = self.hps
+        steps = len(seq)
+        rng = np.random.default_rng(0)
+        pool = ThreadPoolExecutor(max_workers=4)
+        for epoch in range(hp['epochs']):
+            order = rng.permutation(steps)  # Keras fit_generator shuffles batch order (shuffle=True)
+            if self.rank == 0:
+                print('Epoch %d/%d' % (epoch + 1, hp['epochs']))
+            nxt = pool.submit(seq.__getitem__, int(order[0]))
+            for k in range(steps):
+                xb, yb = nxt.result()
+                if k + 1 < steps:
+                    nxt = pool.submit(seq.__getitem__, int(order[k + 1]))
+                x = xb['input1'].astype(np.float32); y = yb['output'].astype(np.float32)
+                if self.world > 1:  # contiguous tower slices, remainder to the last (multi_gpu_model)
+                    per = x.shape[0] // self.world
+                    lo = self.rank * per
+                    hi = x.shape[0] if self.rank == self.world - 1 else lo + per
+                    x, y = x[lo:hi], y[lo:hi]
+                loss = trainer.train_on_batch(torch.from_numpy(x), torch.from_numpy(y), hp['lr'], hp['beta_1'],
+                                              hp['beta_2'], hp.get('decay', 0.0))
+                if self.rank == 0:
+                    print('%d/%d - loss: %.4f' % (k + 1, steps, float(loss.item())))
+        pool.shutdown()
+        if self.rank == 0:
+            print('Save the model.')
+            self.model.save(self.MODEL_PATH)
+        trainer.shutdown()
+
+    # ------------------------------------------------------------------ detect (fd.py:885-949)
+    def detect(self, image):
+        """image: (1,S,S,3) array in [0,1] -> list[BoundBox], ascending score, at most num_cands."""
+        y = self.model.predict_device(np.asarray(image, dtype=np.float32))
+        res = decode_nms(self.model.ctx, y, self.image_size, self.hps['face_conf_th'], self.hps['nms_iou_th'],
+                         self.hps['num_cands'])
+        return to_boundboxes(res, 0)
+
+    def detect_batch(self, images):
+        """(B,S,S,3) -> list of list[BoundBox] (the batched form evaluate/test could use)."""
+        y = self.model.predict_device(np.asarray(images, dtype=np.float32))
+        res = decode_nms(self.model.ctx, y, self.image_size, self.hps['face_conf_th'], self.hps['nms_iou_th'],
+                         self.hps['num_cands'])
+        return [to_boundboxes(res, b) for b in range(y.shape[0])]
+
+    # ------------------------------------------------------------------ evaluate / test
+    def _project_back(self, boxes, geom):
+        """Undo the letterbox (fd.py:700-710)."""
+        h, w, pad_t, _pb, pad_l, _pr = geom
+        S = self.image_size
+        for b in boxes:
+            if w >= h:
+                b.xmin = np.min([b.xmin * w / S, w]); b.xmax = np.min([b.xmax * w / S, w])
+                b.ymin = np.min([np.max([b.ymin - pad_t, 0]) * w / S, h])
+                b.ymax = np.min([np.max([b.ymax - pad_t, 0]) * w / S, h])
+            else:
+                b.xmin = np.min([np.max([b.xmin - pad_l, 0]) * h / S, w])
+                b.xmax = np.min([np.max([b.xmax - pad_l, 0]) * h / S, w])
+                b.ymin = np.min([b.ymin * h / S, h]); b.ymax = np.min([b.ymax * h / S, h])
+
+    @staticmethod
+    def _write_rows(f, file_name, boxes):
+        base = os.path.basename(file_name)
+        for b in boxes[:60]:   # the writers hard-code 60 (fd.py:729, 870)
+            f.write(base + ',' + str(b.xmin) + ',' + str(b.ymin) + ',' + str(b.xmax - b.xmin) + ','
+                    + str(b.ymax - b.ymin) + ',' + str(b.get_score()) + '\n')
+
+    def _files(self, test_path):
+        from .parallel import shard_files
+        names = sorted(glob.glob(os.path.join(test_path, '*.jpg')))
+        return shard_files(names, self.world, self.rank) if self.world > 1 else names
+
+    def _run_file(self, file_name):
+        raw = data._pil_loader(file_name)
+        img, geom = data.letterbox(raw, self.image_size)
+        boxes = self.detect(img[np.newaxis, :])
+        self._project_back(boxes, geom)
+        return raw, boxes
+
+    def evaluate(self):
+        import pandas as pd
+        test_path = self.conf['test_path']
+        out_path = self.conf['output_file_path']
+        res_dir = os.path.join(test_path, 'results')
+        if self.rank == 0:
+            shutil.rmtree(res_dir, ignore_errors=True)
+        os.makedirs(res_dir, exist_ok=True)
+        gt_df = pd.read_csv(os.path.join(test_path, 'validation.csv'))
+        groups = {k: v for k, v in gt_df.groupby('FILE')}
+        files = self._files(test_path)
+        ratios = []
+        if self.world > 1:
+            out_path = out_path + '.rank%d' % self.rank
+        with open(out_path, 'w') as f:
+            for n, file_name in enumerate(files):
+                if DEBUG:
+                    print(n + 1, '/', len(files), file_name)
+                raw, boxes = self._run_file(file_name)
+                self._write_rows(f, file_name, boxes)
+                if len(boxes) == 0:
+                    continue
+                base = os.path.basename(file_name)
+                gt_boxes = []
+                df = groups.get(base)
+                if df is not None:
+                    for i in range(df.shape[0]):
+                        v = df.iloc[i, 3:7].values.astype(np.float64)
+                        if not np.all(v > 0):
+                            continue
+                        xmin, ymin = int(v[0]), int(v[1])
+                        xmax, ymax = int(xmin + v[2] - 1), int(ymin + v[3] - 1)
+                        gt_boxes.append(BoundBox(xmin, ymin, xmax, ymax, objness=1., classes=[1.0]))
+                        if ymax != ymin:
+                            ratios.append((xmax - xmin) / (ymax - ymin))
+                img = draw_boxes(raw, gt_boxes, self.hps['face_conf_th'], (255, 0, 0))
+                img = draw_boxes(img, boxes, self.hps['face_conf_th'], (0, 255, 0))
+                new_name = base[:-4] + '_detected' + base[-4:]
+                print(new_name)
+                from PIL import Image
+                Image.fromarray(img.astype('uint8')).save(os.path.join(res_dir, new_name))
+        pd.DataFrame({'ratio': ratios}).to_csv('ratios.csv' if self.world == 1 else 'ratios.csv.rank%d' % self.rank)
+
+    def test(self):
+        test_path = self.conf['test_path']
+        out_path = self.conf['output_file_path']
+        files = self._files(test_path)
+        if self.world > 1:
+            out_path = out_path + '.rank%d' % self.rank
+        with open(out_path, 'w') as f:
+            for n, file_name in enumerate(files):
+                if DEBUG:
+                    print(n + 1, '/', len(files), file_name)
+                _raw, boxes = self._run_file(file_name)
+                self._write_rows(f, file_name, boxes)
+
+
+def _font():
+    from PIL import ImageFont
+    for name in ('arial.ttf', 'DejaVuSans.ttf'):
+        try:
+            return ImageFont.truetype(name, 15)
+        except OSError:
+            continue
+    return ImageFont.load_default()
+
+
+def draw_boxes(image, boxes, conf_th, color):
+    """Rectangle + score text for every box whose score passes conf_th (the visual contract of
+    the reference's draw_boxes_v3, yolov3_detect.py:505-540)."""
+    from PIL import Image, ImageDraw
+    im = Image.fromarray(np.asarray(image).astype('uint8'))
+    dr = ImageDraw.Draw(im)
+    font = _font()
+    for b in boxes:
+        s = float(b.get_score())
+        if s < conf_th:
+            continue
+        x0, y0, x1, y1 = [float(v) for v in (b.xmin, b.ymin, b.xmax, b.ymax)]
+        dr.rectangle([min(x0, x1), min(y0, y1), max(x0, x1), max(y0, y1)], outline=color, width=2)
+        dr.text((min(x0, x1), max(min(y0, y1) - 16, 0)), '%.3f' % s, fill=color, font=font)
+    return np.asarray(im)
+
+
+def main():
+    """Reads ./face_vijnana_yolov3.json (Windows: _win) and dispatches on fd_conf.mode (fd.py:951-985)."""
+    name = 'face_vijnana_yolov3_win.json' if platform.system() == 'Windows' else 'face_vijnana_yolov3.json'
+    with open(name, 'r') as f:
+        conf = json.load(f)['fd_conf']
+    if conf['mode'] not in ('train', 'evaluate', 'test'):
+        return
+    fd = FaceDetector(conf)
+    ts = time.time()
+    getattr(fd, conf['mode'])()
+    print('Elasped time: {0:f}s'.format(time.time() - ts))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,115 @@
+"""FaceDetector drop-in surface on the GPU: BASELINE config 1 (evaluate on 4 synthetic
+UCCS-format images), detect() against the oracle chain, a tiny train() run, save/load."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _conf(root, mode, image_size=416, batch=2):
+    return {'mode': mode, 'raw_data_path': root, 'test_path': root, 'output_file_path': os.path.join(root, 'solution_fd.csv'),
+            'multi_gpu': False, 'num_gpus': 1, 'yolov3_base_model_load': False, 'model_loading': False,
+            'hps': {'lr': 1e-4, 'beta_1': 0.99, 'beta_2': 0.99, 'decay': 0.0, 'epochs': 1, 'step': 1, 'batch_size': batch,
+                    'face_conf_th': 0.5, 'nms_iou_th': 0.5, 'num_cands': 60, 'face_region_ratio_th': 0.8},
+            'nn_arch': {'image_size': image_size, 'bb_info_c_size': 6}}
+
+
+def test_detect_matches_oracle_chain(tmp_path, monkeypatch):
+    import torch
+    from face_vijnana_yolov3_amd.face_detection import FaceDetector
+    from oracle import net_oracle as no
+    from oracle import postproc as opp
+    monkeypatch.chdir(tmp_path)
+    fd = FaceDetector(_conf(str(tmp_path), 'test'))
+    # random-init weights in inference mode give an arbitrary output scale: normalise the head
+    # kernel to unit output std and bias it so that a healthy number of cells pass the threshold
+    d = fd.model.layers[-1]
+    rng = np.random.default_rng(0)
+    img = rng.uniform(0, 1, (1, 416, 416, 3))
+    y0 = fd.model.predict(img.astype(np.float32))
+    fd.model.params[d['w_off']:d['beta_off']] /= float(y0.std())
+    fd.model.params[d['beta_off']] = 1.0; fd.model.params[d['beta_off'] + 5] = 1.0
+    boxes = fd.detect(img)
+    y = fd.model.predict(img.astype(np.float32))
+    want = opp.detect_postproc(y, 416, 0.5, 0.5, 60)
+    c = int(want['count'][0])
+    assert len(boxes) == c and c > 0
+    assert [(int(b.xmin), int(b.ymin), int(b.xmax), int(b.ymax)) for b in boxes] == [tuple(r) for r in want['boxes'][0, :c]]
+    assert np.array_equal(np.array([b.classes[0] for b in boxes], np.float32), want['score'][0, :c])
+    assert all(type(b.xmin) is np.int64 for b in boxes) and boxes[0].get_label() == 0
+    # network output itself against the torch-CPU oracle (fp32 tolerance, 52 layers deep)
+    yr, _ = no.forward(fd.model.params.cpu().double(), fd.model.state.cpu().double(), torch.from_numpy(img), training=False)
+    y32, _ = no.forward(fd.model.params.cpu(), fd.model.state.cpu(), torch.from_numpy(img).float(), training=False)
+    e_gpu = np.abs(y - yr.numpy()).max(); e_cpu = (y32.double() - yr).abs().max().item()
+    assert e_gpu <= 4 * e_cpu + 1e-6 * max(1.0, yr.abs().max().item())
+    # callers mutate the boxes in place (fd.py:700-710)
+    boxes[0].xmin = 1.5
+    assert boxes[0].xmin == 1.5
+
+
+def test_config1_evaluate_plumbing(tmp_path, monkeypatch):
+    from face_vijnana_yolov3_amd import data
+    from face_vijnana_yolov3_amd.face_detection import FaceDetector
+    monkeypatch.chdir(tmp_path)
+    root = str(tmp_path / 'val'); os.makedirs(root)
+    data.make_synthetic_uccs(root, n_images=4, seed=0, csv_name='validation.csv')
+    fd = FaceDetector(_conf(root, 'evaluate'))
+    d = fd.model.layers[-1]
+    fd.model.params[d['w_off']:d['beta_off']] = 0          # output = bias: every cell fires
+    fd.model.params[d['beta_off']] = 3.0; fd.model.params[d['beta_off'] + 5] = 3.0
+    fd.model.params[d['beta_off'] + 1] = 0.5; fd.model.params[d['beta_off'] + 2] = 0.5
+    fd.model.params[d['beta_off'] + 3] = 0.05; fd.model.params[d['beta_off'] + 4] = 0.05
+    fd.evaluate()
+    rows = [l.strip().split(',') for l in open(os.path.join(root, 'solution_fd.csv'))]
+    assert len(rows) > 0 and all(len(r) == 6 for r in rows)
+    names = {r[0] for r in rows}
+    assert names <= {'synth_%04d.jpg' % k for k in range(4)}
+    for r in rows:
+        x, y, w, h, s = [float(v) for v in r[1:]]
+        assert x >= 0 and y >= 0 and w >= 0 and h >= 0 and 0.5 <= s <= 1.0
+    per_file = {n: sum(1 for r in rows if r[0] == n) for n in names}
+    assert max(per_file.values()) <= 60
+    assert len(os.listdir(os.path.join(root, 'results'))) == len(names)
+    assert os.path.exists('ratios.csv')
+    # test(): same rows, no drawings
+    conf = _conf(root, 'test'); conf['output_file_path'] = os.path.join(root, 'solution_test.csv')
+    fd.conf = conf
+    fd.test()
+    assert open(conf['output_file_path']).read() == open(os.path.join(root, 'solution_fd.csv')).read()
+
+
+def test_tiny_train_save_load(tmp_path, monkeypatch):
+    import torch
+    from face_vijnana_yolov3_amd import data
+    from face_vijnana_yolov3_amd.face_detection import FaceDetector
+    monkeypatch.chdir(tmp_path)
+    root = str(tmp_path / 'train'); os.makedirs(root)
+    data.make_synthetic_uccs(root, n_images=5, seed=1, csv_name='training.csv')
+    conf = _conf(root, 'train', image_size=96, batch=2)
+    conf['hps']['epochs'] = 2
+    fd = FaceDetector(conf)
+    p0 = fd.model.params.clone()
+    fd.train()
+    assert conf['hps']['step'] == 3 and fd.model.iterations == 6
+    assert not torch.equal(p0, fd.model.params) and torch.isfinite(fd.model.params).all()
+    assert os.path.exists(FaceDetector.MODEL_PATH)
+    conf2 = _conf(root, 'test', image_size=96); conf2['model_loading'] = True
+    fd2 = FaceDetector(conf2)
+    assert torch.equal(fd2.model.params, fd.model.params) and torch.equal(fd2.model.state, fd.model.state)
+    assert fd2.model.iterations == 6 and torch.equal(fd2.model.m, fd.model.m)
+    x = np.random.default_rng(0).uniform(0, 1, (1, 96, 96, 3))
+    assert np.array_equal(fd.model.predict(x), fd2.model.predict(x))
+
+
+def test_main_reads_json_from_cwd(tmp_path, monkeypatch):
+    from face_vijnana_yolov3_amd import data, face_detection
+    monkeypatch.chdir(tmp_path)
+    root = str(tmp_path / 'val'); os.makedirs(root)
+    data.make_synthetic_uccs(root, n_images=2, seed=2, csv_name='validation.csv')
+    conf = _conf(root, 'test', image_size=96)
+    json.dump({'fd_conf': conf, 'fi_conf': {}}, open('face_vijnana_yolov3.json', 'w'))
+    face_detection.main()
+    assert os.path.exists(conf['output_file_path'])

@@ -1,0 +1,93 @@
+"""Host-side (CPU) pieces of the product against the golden vectors and by property."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from face_vijnana_yolov3_amd import data, weights
+
+
+def test_encode_gt_matches_reference_golden(golden_dir):
+    import pandas as pd
+    g = np.load(os.path.join(golden_dir, 'gt_encoder.npz'))
+    df = pd.read_csv(io.StringIO(str(g['csv'])))
+    for k, f in enumerate(g['files']):
+        rows = df[df['FILE'] == str(f)].iloc[:, 3:7].values
+        gt = data.encode_gt(rows, int(g['hw'][k][0]), int(g['hw'][k][1]), 416, 13)
+        np.testing.assert_array_equal(gt, g['gt'][k], err_msg=str(f))
+
+
+def test_letterbox_geometry_and_pixels():
+    for (h, w) in [(300, 500), (500, 300), (416, 416), (601, 1000), (123, 124), (1080, 1920)]:
+        w_p, h_p, pt, pb, pl, pr = data.letterbox_geometry(h, w, 416)
+        assert h_p + pt + pb == 416 and w_p + pl + pr == 416
+        assert (pb - pt) in (0, 1) and (pr - pl) in (0, 1)      # extra row/col bottom/right
+        img, geom = data.letterbox(np.full((h, w, 3), 128, np.uint8), 416)
+        assert img.shape == (416, 416, 3) and geom[:2] == (h, w)
+        inner = img[pt:416 - pb, pl:416 - pr]
+        np.testing.assert_allclose(inner, 128 / 255, atol=1e-12)  # bicubic weights sum to 1
+        assert img[:pt].sum() == 0 and img[:, :pl].sum() == 0
+    # same size: identity
+    rng = np.random.default_rng(0)
+    raw = rng.integers(0, 256, (416, 416, 3), dtype=np.uint8)
+    np.testing.assert_allclose(data.letterbox(raw, 416)[0], raw / 255, atol=1e-12)
+
+
+def test_training_sequence_contract(tmp_path):
+    df = data.make_synthetic_uccs(str(tmp_path), n_images=5, seed=3)
+    hps = {'batch_size': 2, 'step': 1}
+    seq = data.TrainingSequence(str(tmp_path), hps, {'image_size': 64, 'bb_info_c_size': 6})
+    assert hps['step'] == 3 and len(seq) == 3                      # overwritten: ceil(5/2)
+    assert seq.file_names == sorted(df['FILE'].unique())
+    x, y = seq[0]
+    assert x['input1'].shape == (2, 64, 64, 3) and y['output'].shape == (2, 2, 2, 6)
+    x, y = seq[2]
+    assert x['input1'].shape[0] == 1                                # short last batch
+    assert y['output'][..., 0].sum() >= 1
+
+
+def test_darknet_reader_matches_reference_golden_and_roundtrip(golden_dir, tmp_path):
+    g = np.load(os.path.join(golden_dir, 'weight_reader.npz'))
+    spec = [(0, 3, 3, 4), (1, 3, 4, 8), (3, 1, 8, 6)]
+    layers, off, soff = [], 0, 0
+    for idx, k, cin, cout in spec:
+        d = dict(darknet_index=idx, ksize=k, cin=cin, cout=cout, has_bn=1, w_off=off)
+        off += cout * k * k * cin
+        d['gamma_off'] = off; off += cout
+        d['beta_off'] = off; off += cout
+        d['mean_off'] = soff; soff += cout
+        d['var_off'] = soff; soff += cout
+        layers.append(d)
+    for tag in ('v2', 'v1'):
+        p, s = weights.read_darknet_base(g[tag + '_file'].tobytes(), layers, off, soff)
+        kw = weights.keras_weights(layers, p, s)
+        for d in layers:
+            i = d['darknet_index']
+            np.testing.assert_array_equal(kw['conv_%d' % i][0], g['%s_conv_%d_0' % (tag, i)])
+            for j in range(4):
+                np.testing.assert_array_equal(kw['bnorm_%d' % i][j], g['%s_bnorm_%d_%d' % (tag, i, j)])
+    path = str(tmp_path / 'synthetic.weights')
+    weights.write_darknet_base(path, layers, p, s)
+    p2, s2 = weights.read_darknet_base(path, layers, off, soff)
+    np.testing.assert_array_equal(p, p2); np.testing.assert_array_equal(s, s2)
+    with pytest.raises(ValueError):
+        weights.read_darknet_base(open(path, 'rb').read()[:100], layers, off, soff)
+
+
+def test_layer_table_without_gpu():
+    from face_vijnana_yolov3_amd.engine import layer_table
+    from oracle import net_oracle as no
+    t = layer_table()
+    ents, n, ns = no.param_layout()
+    assert len(t) == 53 and t[-1]['role'] == 3 and t[-1]['beta_off'] + 6 == n
+    assert [d['darknet_index'] for d in t[:-1]] == [e['idx'] for e in ents[:-1]]
+    assert [d['in_div'] for d in t if d['stride'] == 2] == [1, 2, 4, 8, 16] and t[-1]['out_div'] == 32
+
+
+def test_shard_files():
+    from face_vijnana_yolov3_amd.parallel import shard_files
+    names = ['f%d' % i for i in range(10)]
+    parts = [shard_files(names, 4, r) for r in range(4)]
+    assert sum(parts, []) == names and max(len(p) for p in parts) == 3
+    assert shard_files(names[:2], 4, 3) == []
