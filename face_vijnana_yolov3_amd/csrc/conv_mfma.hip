@@ -21,6 +21,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128;
 constexpr int BK = 32;
@@ -127,6 +128,13 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
         __syncthreads();
         compute(As[0], Bs[0]);
     } else {
+        // Operand rows come through buffer descriptors: an out-of-range offset (row outside the
+        // image / the problem) returns zeros in hardware, so the K loop has no per-load branches.
+        constexpr unsigned OOB = 0x80000000u;  // >= num_records for every tensor we accept (< 2^31 bytes)
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)a.x, 0, (int)((unsigned)a.B * a.Hin * a.Win * a.Cin * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)a.w, 0, (int)((unsigned)a.Nout * a.Tw * a.Cin * 4u), 0x00020000);
         const int col4 = (tid & 7) * 4;
         int a_pix[4], a_oh[4], a_ow[4];
 #pragma unroll
@@ -139,17 +147,17 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
                 a_pix[p] = 0; a_oh[p] = -(1 << 28); a_ow[p] = 0;
             }
         }
-        int b_row[BL];
+        unsigned b_row[BL];
 #pragma unroll
         for (int p = 0; p < BL; ++p) {
             int n = n0 + (tid >> 3) + 32 * p;
-            b_row[p] = n < a.Nout ? n * a.Tw * a.Cin : -1;
+            b_row[p] = n < a.Nout ? (unsigned)(n * a.Tw * a.Cin + col4) * 4u : OOB;
         }
 
         const int cpk = a.Cin / BK;
         const int nk = taps.n * cpk;
-        float4 ra[4], rb[BL];
-        int a_off[4];
+        u32x4 ra[4], rb[BL];
+        unsigned a_off[4];
         int t = 0, ci = 0;
         auto set_tap = [&](int tp) {
             const int dh = taps.dh[tp], dw = taps.dw[tp];
@@ -157,31 +165,48 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
             for (int p = 0; p < 4; ++p) {
                 int ih = a_oh[p] + dh, iw = a_ow[p] + dw;
                 bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
-                a_off[p] = ok ? ((a_pix[p] + ih) * a.Win + iw) * a.Cin + col4 : -1;
+                a_off[p] = ok ? (unsigned)(((a_pix[p] + ih) * a.Win + iw) * a.Cin + col4) * 4u : OOB;
             }
         };
         auto load = [&]() {
-            const int c0 = ci * BK;
+            const int c0b = ci * BK * 4;
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-                ra[p] = a_off[p] >= 0 ? *reinterpret_cast<const float4*>(a.x + a_off[p] + c0)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-            const int wofs = taps.wslot[t] * a.Cin + c0 + col4;
+            for (int p = 0; p < 4; ++p) ra[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, a_off[p], c0b, 0);
+            const int wofs = (taps.wslot[t] * a.Cin) * 4 + c0b;
 #pragma unroll
-            for (int p = 0; p < BL; ++p)
-                rb[p] = b_row[p] >= 0 ? *reinterpret_cast<const float4*>(a.w + b_row[p] + wofs)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p = 0; p < BL; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_row[p], wofs, 0);
         };
         auto stage = [&](int buf) {
 #pragma unroll
             for (int p = 0; p < 4; ++p)
-                *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * p) * LDT + col4]) = ra[p];
+                *reinterpret_cast<u32x4*>(&As[buf][((tid >> 3) + 32 * p) * LDT + col4]) = ra[p];
 #pragma unroll
             for (int p = 0; p < BL; ++p)
-                *reinterpret_cast<float4*>(&Bs[buf][((tid >> 3) + 32 * p) * LDT + col4]) = rb[p];
+                *reinterpret_cast<u32x4*>(&Bs[buf][((tid >> 3) + 32 * p) * LDT + col4]) = rb[p];
         };
         auto advance = [&]() {
             if (++ci == cpk) { ci = 0; ++t; if (t < taps.n) set_tap(t); }
+        };
+        // fragment double-buffering: the LDS reads of K-chunk c+1 are issued before the MFMAs of
+        // chunk c, and the next tile is staged into the other LDS buffer while chunks 2-3 compute
+        const int arow = (wm * WTM + (lane & 31)) * LDT + (lane >> 5) * 4;
+        const int brow = (wn * WTN + (lane & 31)) * LDT + (lane >> 5) * 4;
+        auto readfrag = [&](const float* __restrict__ Asm, const float* __restrict__ Bsm, int kc, float4 (&af)[MB], float4 (&bf)[NB]) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i) af[i] = *reinterpret_cast<const float4*>(&Asm[arow + i * 32 * LDT + kc * 8]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bsm[brow + j * 32 * LDT + kc * 8]);
+        };
+        auto mfma_chunk = [&](const float4 (&af)[MB], const float4 (&bf)[NB]) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
         };
 
         set_tap(0);
@@ -193,8 +218,16 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
             const int cur = s & 1;
             const bool more = s + 1 < nk;
             if (more) load();
-            compute(As[cur], Bs[cur]);
+            float4 af0[MB], bf0[NB], af1[MB], bf1[NB];
+            readfrag(As[cur], Bs[cur], 0, af0, bf0);
+            readfrag(As[cur], Bs[cur], 1, af1, bf1);
+            mfma_chunk(af0, bf0);
+            readfrag(As[cur], Bs[cur], 2, af0, bf0);
+            mfma_chunk(af1, bf1);
+            readfrag(As[cur], Bs[cur], 3, af1, bf1);
             if (more) { stage(cur ^ 1); advance(); }
+            mfma_chunk(af0, bf0);
+            mfma_chunk(af1, bf1);
             __syncthreads();
         }
     }
@@ -270,10 +303,10 @@ int fv_conv_mtiles(int M, int Nout) { (void)Nout; return (M + BM - 1) / BM; }
 int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
     FV_REQUIRE(ctx, a.x && a.w && a.out, "conv: NULL tensor");
     FV_REQUIRE(ctx, a.M > 0 && a.Nout > 0 && a.nclass >= 1 && a.nclass <= 4, "conv: bad problem size");
-    FV_REQUIRE(ctx, (long long)a.B * a.Hin * a.Win * a.Cin < (1ll << 31) &&
+    FV_REQUIRE(ctx, (long long)a.B * a.Hin * a.Win * a.Cin < (1ll << 29) &&
                         (long long)a.B * a.Hout * a.Wout * a.Nout < (1ll << 31) &&
-                        (long long)a.Nout * a.Tw * a.Cin < (1ll << 31),
-               "conv: tensor exceeds 2^31 elements");
+                        (long long)a.Nout * a.Tw * a.Cin < (1ll << 29),
+               "conv: input/weight tensor exceeds 2^29 elements (2 GiB buffer descriptor) or output 2^31");
     FV_REQUIRE(ctx, !(a.epi & FV_EPI_STATS) || (a.psum && a.psq && a.nclass == 1), "conv: stats need psum/psq");
     FV_REQUIRE(ctx, !(a.epi & FV_EPI_ADD) || a.addend, "conv: FV_EPI_ADD needs addend");
     const bool gather = a.Cin % BK != 0;

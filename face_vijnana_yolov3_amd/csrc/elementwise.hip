@@ -7,7 +7,6 @@
 
 namespace {
 
-constexpr int RED_ROWS = 32;  // row lanes of the 1024-thread column reducers
 
 // ---------------------------------------------------------------- BN finalize (forward, training)
 // partial sums [mtiles][C] (from the conv epilogue) -> mean, invstd, scale, shift, moving stats.
@@ -17,16 +16,21 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                                            float* __restrict__ scale_out, float* __restrict__ shift_out,
                                                            float* __restrict__ moving_mean, float* __restrict__ moving_var) {
-    __shared__ double ssum[RED_ROWS][33], ssq[RED_ROWS][33];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    // block = 8 channels x 128 row lanes (many blocks even for 32-channel layers with 27k partial rows)
+    __shared__ double ssum[128][9], ssq[128][9];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int r = rl; r < mtiles; r += RED_ROWS) { s += (double)psum[(size_t)r * C + c]; q += (double)psq[(size_t)r * C + c]; }
+        for (int r = rl; r < mtiles; r += 128) { s += (double)psum[(size_t)r * C + c]; q += (double)psq[(size_t)r * C + c]; }
     ssum[rl][cl] = s; ssq[rl][cl] = q;
     __syncthreads();
+    for (int st = 64; st > 0; st >>= 1) {   // fixed-order tree: deterministic
+        if (rl < st) { ssum[rl][cl] += ssum[rl + st][cl]; ssq[rl][cl] += ssq[rl + st][cl]; }
+        __syncthreads();
+    }
     if (rl == 0 && c < C) {
-        for (int r = 1; r < RED_ROWS; ++r) { s += ssum[r][cl]; q += ssq[r][cl]; }
+        s = ssum[0][cl]; q = ssq[0][cl];
         double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -118,18 +122,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 // pass 1b: reduce the chunk partials in double -> dbeta, dgamma (written into the flat grad vector)
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ pdb, const float* __restrict__ pdg,
                                                                int chunks, int C, float* __restrict__ dbeta, float* __restrict__ dgamma) {
-    __shared__ double s1[RED_ROWS][33], s2[RED_ROWS][33];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double s1[128][9], s2[128][9];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double a = 0.0, b = 0.0;
     if (c < C)
-        for (int r = rl; r < chunks; r += RED_ROWS) { a += (double)pdb[(size_t)r * C + c]; b += (double)pdg[(size_t)r * C + c]; }
+        for (int r = rl; r < chunks; r += 128) { a += (double)pdb[(size_t)r * C + c]; b += (double)pdg[(size_t)r * C + c]; }
     s1[rl][cl] = a; s2[rl][cl] = b;
     __syncthreads();
-    if (rl == 0 && c < C) {
-        for (int r = 1; r < RED_ROWS; ++r) { a += s1[r][cl]; b += s2[r][cl]; }
-        dbeta[c] = (float)a; dgamma[c] = (float)b;
+    for (int st = 64; st > 0; st >>= 1) {
+        if (rl < st) { s1[rl][cl] += s1[rl + st][cl]; s2[rl][cl] += s2[rl + st][cl]; }
+        __syncthreads();
     }
+    if (rl == 0 && c < C) { dbeta[c] = (float)s1[0][cl]; dgamma[c] = (float)s2[0][cl]; }
 }
 
 // pass 2: dz = scale * (gy - dbeta/M - xhat * dgamma/M)
@@ -253,7 +258,7 @@ int fv_ew_bn_finalize(fv_ctx* ctx, const float* psum, const float* psq, int mtil
                       const float* beta, float eps, float momentum, float* mean, float* invstd, float* scale, float* shift,
                       float* moving_mean, float* moving_var) {
     FvProfScope ps(ctx, "bn_finalize_kernel", 0.0, 8.0 * mtiles * C);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, ctx->stream, psum, psq, mtiles, C, count, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, ctx->stream, psum, psq, mtiles, C, count, gamma,
                        beta, eps, momentum, mean, invstd, scale, shift, moving_mean, moving_var);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
@@ -297,7 +302,7 @@ int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale
                            (int)rpb, leaky, pdb, pdg);
     }
     FV_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, ctx->stream, pdb, pdg, chunks, C, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, ctx->stream, pdb, pdg, chunks, C, dbeta, dgamma);
     FV_LAUNCH_CHECK(ctx);
     long long n4 = rows * C / 4;
     FvProfScope ps(ctx, "bn_bwd_apply_kernel", 0.0, 12.0 * rows * C);

@@ -52,21 +52,23 @@ class BucketReducer(object):
 
 
 class DataParallelTrainer(object):
-    def __init__(self, engine, world_size=None, rank=None, bucket_bytes=32 << 20):
+    def __init__(self, engine, world_size=None, rank=None, bucket_bytes=32 << 20, force_bucket_path=False):
         self.eng = engine
         self.world = int(world_size if world_size is not None else os.environ.get('WORLD_SIZE', 1))
         self.rank = int(rank if rank is not None else os.environ.get('RANK', 0))
         self.bucket_bytes = bucket_bytes
         self.comm = None
         self.reducer = None
+        self.bucketed = self.world > 1 or force_bucket_path  # force: exercise the stream/bucket path on 1 GPU
+        if self.bucketed:
+            self.comm = torch.cuda.Stream(device=engine.dev)
+            engine.ensure_optimizer()
+            self.reducer = BucketReducer(engine.grads, self.world, bucket_bytes, self._launch)
         if self.world > 1:
             if not dist.is_initialized():
                 os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
                 os.environ.setdefault('MASTER_PORT', '29500')
                 dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=engine.dev)
-            self.comm = torch.cuda.Stream(device=engine.dev)
-            engine.ensure_optimizer()
-            self.reducer = BucketReducer(engine.grads, self.world, bucket_bytes, self._launch)
             # identical start on every rank
             dist.broadcast(engine.params, 0)
             dist.broadcast(engine.state, 0)
@@ -77,12 +79,13 @@ class DataParallelTrainer(object):
         ev.record(torch.cuda.current_stream(self.eng.dev))
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(ev)
-            dist.all_reduce(view, op=dist.ReduceOp.SUM)
+            if self.world > 1:
+                dist.all_reduce(view, op=dist.ReduceOp.SUM)
             view.mul_(1.0 / self.world)
 
     def train_on_batch(self, x, y, lr, beta_1, beta_2, decay=0.0):
         eng = self.eng
-        if self.world == 1:
+        if not self.bucketed:
             return eng.train_on_batch(x, y, lr, beta_1, beta_2, decay)
         self.reducer.reset()
         loss = eng.forward_backward(x, y, on_bucket=self.reducer.on_range)
@@ -92,7 +95,8 @@ class DataParallelTrainer(object):
             # order); we keep ranks identical by averaging (parity unpinned)
             ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(eng.dev))
             self.comm.wait_event(ev)
-            dist.all_reduce(eng.state, op=dist.ReduceOp.SUM)
+            if self.world > 1:
+                dist.all_reduce(eng.state, op=dist.ReduceOp.SUM)
             eng.state.mul_(1.0 / self.world)
         torch.cuda.current_stream(eng.dev).wait_stream(self.comm)
         eng.adam_step(lr, beta_1, beta_2, decay)

@@ -126,3 +126,28 @@ def test_workspace_too_small_is_reported(eng):
     assert rc == -3 and b'workspace' in lib().fv_last_error(eng.ctx.handle)
     rc = lib().fv_forward_infer(eng.ctx.handle, ptr(eng.params), ptr(eng.state), ptr(x), 1, 70, ptr(ws), ws.numel(), ptr(y))
     assert rc == -1
+
+
+def test_bucketed_side_stream_path_equals_plain(eng):
+    """The N>1 code path (bucket callback -> event -> side stream -> wait -> Adam) on one GPU with the
+    collective elided: must reproduce the plain path up to float-atomic ordering in dW."""
+    from face_vijnana_yolov3_amd.engine import Engine
+    from face_vijnana_yolov3_amd.parallel import DataParallelTrainer
+    from oracle import net_oracle as no
+    p64, s64, x, yt = _setup(11, 4, 96)
+    outs = []
+    for force in (False, True):
+        eng.set_params(p64.float(), s64.float())
+        eng.iterations = 0; eng.m = eng.v = eng.grads = None
+        tr = DataParallelTrainer(eng, world_size=1, rank=0, bucket_bytes=8 << 20, force_bucket_path=force)
+        for _ in range(2):
+            loss = tr.train_on_batch(x.float(), yt.float(), 1e-4, 0.99, 0.99)
+        torch.cuda.synchronize()
+        if force:
+            cover = sorted(tr.reducer.launched)
+            assert cover[0][0] == 0 and cover[-1][1] == eng.n_params and len(cover) >= 5
+            assert all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
+        outs.append((loss.item(), eng.params.clone(), eng.state.clone()))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-4 * abs(outs[0][0])
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=0, atol=5e-4)   # 2 Adam steps of lr 1e-4: |dp| <= 2e-4
+    torch.testing.assert_close(outs[0][2], outs[1][2], rtol=1e-4, atol=1e-5)
