@@ -17,6 +17,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KP = 32;  // pixels per chunk
 
 template <int TM, int TN, bool QUAD, bool GATHER>
@@ -53,20 +54,46 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    float4 ra[AL], rb[BL];
-    auto load = [&](int ch) {
-        const int mbase = ch * KP;
+    // Operand rows come through buffer descriptors (out-of-range offset -> zeros, no branches).
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((unsigned)a.B * a.Hin * a.Win * a.Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.dy, 0, (int)((unsigned)a.M * a.Ndy * 4u), 0x00020000);
+
+    // per-thread rows of the A' (dy) and B' (x) tiles; the pixel coordinates of the B' rows are
+    // advanced incrementally by KP pixels per chunk (no integer division in the loop)
+    unsigned a_off[AL];   // byte offset of dy row at chunk ch_begin (OOB if the channel group is outside N)
+    int a_m[AL];
+#pragma unroll
+    for (int p = 0; p < AL; ++p) {
+        int f = tid + 256 * p, row = f / (TM / 4), col = (f % (TM / 4)) * 4;
+        a_m[p] = ch_begin * KP + row;
+        a_off[p] = (n0 + col < a.N) ? (unsigned)(n0 + col) * 4u : OOB;
+    }
+    int b_b[BL], b_oh[BL], b_ow[BL], b_m[BL], b_col[BL];
+    if constexpr (!GATHER) {
+#pragma unroll
+        for (int p = 0; p < BL; ++p) {
+            int f = tid + 256 * p, row = f / (TN / 4);
+            b_col[p] = (f % (TN / 4)) * 4;
+            int m = ch_begin * KP + row;
+            b_m[p] = m;
+            b_b[p] = m / HWl; int rem = m - b_b[p] * HWl; b_oh[p] = rem / a.Wl; b_ow[p] = rem - b_oh[p] * a.Wl;
+        }
+    }
+    u32x4 ra[AL], rb[BL];
+    auto load = [&]() {
 #pragma unroll
         for (int p = 0; p < AL; ++p) {
-            int f = tid + 256 * p, row = f / (TM / 4), col = (f % (TM / 4)) * 4;
-            int m = mbase + row, n = n0 + col;
-            ra[p] = (m < a.M && n < a.N) ? *reinterpret_cast<const float4*>(a.dy + (size_t)m * a.Ndy + n)
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned off = (a_m[p] < a.M && a_off[p] != OOB) ? (unsigned)a_m[p] * (unsigned)a.Ndy * 4u + a_off[p] : OOB;
+            ra[p] = __builtin_amdgcn_raw_buffer_load_b128(yr, off, 0, 0);
+            a_m[p] += KP;
         }
         if constexpr (GATHER) {
             // row = pixel, 32 k-slots = 9 taps x Cin (3x3, pad 1, stride 1), zero padded
             int row = tid >> 3, kq = (tid & 7) * 4;
-            int m = mbase + row;
+            int m = a_m[0] - KP - (tid / (TM / 4)) + row;   // chunk base + row
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (m < a.M) {
                 int b = m / HWl, rem = m - b * HWl, oh = rem / a.Wl, ow = rem - oh * a.Wl;
@@ -81,20 +108,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
                     }
                 }
             }
-            rb[0] = make_float4(v[0], v[1], v[2], v[3]);
+            rb[0] = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
         } else {
 #pragma unroll
             for (int p = 0; p < BL; ++p) {
-                int f = tid + 256 * p, row = f / (TN / 4), col = (f % (TN / 4)) * 4;
-                int m = mbase + row;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < a.M) {
-                    int b = m / HWl, rem = m - b * HWl, oh = rem / a.Wl, ow = rem - oh * a.Wl;
-                    int ih = oh * a.is + dh, iw = ow * a.is + dw;
-                    if ((unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win)
-                        v = *reinterpret_cast<const float4*>(a.x + ((size_t)(b * a.Hin + ih) * a.Win + iw) * a.Cin + c0 + col);
-                }
-                rb[p] = v;
+                int ih = b_oh[p] * a.is + dh, iw = b_ow[p] * a.is + dw;
+                bool ok = b_m[p] < a.M && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+                unsigned off = ok ? (unsigned)(((b_b[p] * a.Hin + ih) * a.Win + iw) * a.Cin + c0 + b_col[p]) * 4u : OOB;
+                rb[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+                // advance this row by KP pixels
+                b_m[p] += KP; b_ow[p] += KP;
+                while (b_ow[p] >= a.Wl) { b_ow[p] -= a.Wl; ++b_oh[p]; }
+                while (b_oh[p] >= a.Hl) { b_oh[p] -= a.Hl; ++b_b[p]; }
             }
         }
     };
@@ -102,46 +127,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
 #pragma unroll
         for (int p = 0; p < AL; ++p) {
             int f = tid + 256 * p, row = f / (TM / 4), col = (f % (TM / 4)) * 4;
-            *reinterpret_cast<float4*>(&As[buf][row * LDA + col]) = ra[p];
+            *reinterpret_cast<u32x4*>(&As[buf][row * LDA + col]) = ra[p];
         }
         if constexpr (GATHER) {
-            *reinterpret_cast<float4*>(&Bs[buf][(tid >> 3) * LDB + (tid & 7) * 4]) = rb[0];
+            *reinterpret_cast<u32x4*>(&Bs[buf][(tid >> 3) * LDB + (tid & 7) * 4]) = rb[0];
         } else {
 #pragma unroll
             for (int p = 0; p < BL; ++p) {
                 int f = tid + 256 * p, row = f / (TN / 4), col = (f % (TN / 4)) * 4;
-                *reinterpret_cast<float4*>(&Bs[buf][row * LDB + col]) = rb[p];
+                *reinterpret_cast<u32x4*>(&Bs[buf][row * LDB + col]) = rb[p];
             }
         }
     };
-    auto compute = [&](const float* __restrict__ Asm, const float* __restrict__ Bsm) {
-        constexpr int KW = QUAD ? KP : KP / 4;  // pixels this wave consumes per chunk
-        const int kbase = QUAD ? 0 : wave * KW;
+    constexpr int KW = QUAD ? KP : KP / 4;  // pixels this wave consumes per chunk
+    const int kbase = QUAD ? 0 : wave * KW;
+    const int aoff = wm * WTM + (lane & 31), boff = wn * WTN + (lane & 31);
+    // one k-pair (2 pixels): lanes 0-31 take pixel k, lanes 32-63 pixel k+1
+    auto step = [&](const float* __restrict__ Asm, const float* __restrict__ Bsm, int kk) {
+        const int k = kbase + kk + (lane >> 5);
+        float af[MB], bf[NB];
 #pragma unroll
-        for (int kk = 0; kk < KW; kk += 2) {
-            const int k = kbase + kk + (lane >> 5);
-            float af[MB], bf[NB];
+        for (int i = 0; i < MB; ++i) af[i] = Asm[k * LDA + aoff + i * 32];
 #pragma unroll
-            for (int i = 0; i < MB; ++i) af[i] = Asm[k * LDA + wm * WTM + i * 32 + (lane & 31)];
+        for (int j = 0; j < NB; ++j) bf[j] = Bsm[k * LDB + boff + j * 32];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) bf[j] = Bsm[k * LDB + wn * WTN + j * 32 + (lane & 31)];
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
+            for (int j = 0; j < NB; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     };
 
-    load(ch_begin);
+    load();
     stage(0);
     __syncthreads();
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int cur = (ch - ch_begin) & 1;
         const bool more = ch + 1 < ch_end;
-        if (more) load(ch + 1);
-        compute(As[cur], Bs[cur]);
-        if (more) stage(cur ^ 1);
+        if (more) load();
+#pragma unroll
+        for (int kk = 0; kk < KW / 2; kk += 2) step(As[cur], Bs[cur], kk);
+        if (more) stage(cur ^ 1);   // next tile lands in the other buffer while the second half computes
+#pragma unroll
+        for (int kk = KW / 2; kk < KW; kk += 2) step(As[cur], Bs[cur], kk);
         __syncthreads();
     }
 
@@ -192,8 +219,8 @@ int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
 int fv_wgrad_launch(fv_ctx* ctx, const FvWgradArgs& a) {
     FV_REQUIRE(ctx, a.x && a.dy && a.dw, "wgrad: NULL tensor");
     FV_REQUIRE(ctx, a.M > 0 && a.N > 0 && a.Ndy >= a.N && a.Ndy % 4 == 0, "wgrad: bad sizes (Ndy must be a multiple of 4)");
-    FV_REQUIRE(ctx, (long long)a.B * a.Hin * a.Win * a.Cin < (1ll << 31) && (long long)a.M * a.Ndy < (1ll << 31),
-               "wgrad: tensor exceeds 2^31 elements");
+    FV_REQUIRE(ctx, (long long)a.B * a.Hin * a.Win * a.Cin < (1ll << 29) && (long long)a.M * a.Ndy < (1ll << 29),
+               "wgrad: tensor exceeds 2^29 elements (2 GiB buffer descriptor)");
     if (a.Cin % 32 != 0) {
         FV_REQUIRE(ctx, 9 * a.Cin <= 32 && a.is == 1 && a.Hl == a.Hin && a.Wl == a.Win && a.taps.n == 9,
                    "wgrad: Cin=%d only supported as 3x3 stride-1 pad-1 with 9*Cin<=32", a.Cin);
