@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=1)
     ap.add_argument('--profile-steps', type=int, default=2)
+    ap.add_argument('--no-overlap', action='store_true', help='serialise wgrad on the main stream (A/B aid)')
     return ap.parse_args()
 
 
@@ -83,6 +84,8 @@ def main():
 
     eng = Engine(local_rank)
     eng.init_synthetic(seed=7)                      # identical weights on every rank
+    if args.no_overlap:
+        eng.ctx.set_overlap(False)
     trainer = DataParallelTrainer(eng, world_size=world, rank=rank)  # inits RCCL when world > 1
     B, S = args.batch, args.image_size
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)

@@ -61,6 +61,7 @@ BUCKET_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 def _declare(L):
     i32, i64, f32, f64, vp, sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, c_void_p, ctypes.c_size_t
     sig = {
+        'fv_set_overlap': (i32, [vp, i32]),
         'fv_profile_enable': (i32, [vp, i32]),
         'fv_profile_collect': (i32, [vp, ctypes.POINTER(ProfileRec), i32, ctypes.POINTER(i32)]),
         'fv_num_layers': (i32, []),
@@ -115,6 +116,9 @@ class Context:
 
     def set_stream(self, stream_ptr):
         self.check(lib().fv_set_stream(self._h, c_void_p(stream_ptr)), 'fv_set_stream')
+
+    def set_overlap(self, on):
+        self.check(lib().fv_set_overlap(self._h, 1 if on else 0), 'fv_set_overlap')
 
     def profile(self, on):
         self.check(lib().fv_profile_enable(self._h, 1 if on else 0), 'fv_profile_enable')

@@ -17,6 +17,11 @@ int fv_fail(fv_ctx* ctx, int code, const char* fmt, ...) {
 fv_ctx::~fv_ctx() {
     for (auto& r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : ev_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) {
+        if (ev_dz[i]) (void)hipEventDestroy(ev_dz[i]);
+        if (ev_wg[i]) (void)hipEventDestroy(ev_wg[i]);
+    }
+    if (side) (void)hipStreamDestroy(side);
 }
 
 static hipEvent_t take_event(fv_ctx* c) {
@@ -41,6 +46,12 @@ FvProfScope::~FvProfScope() {
 extern "C" {
 
 int fv_abi_version(void) { return 1; }
+
+int fv_set_overlap(fv_ctx* ctx, int on) {
+    if (!ctx) return FV_ERR_INVALID;
+    ctx->overlap = on != 0;
+    return FV_OK;
+}
 
 int fv_profile_enable(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;
@@ -92,6 +103,11 @@ int fv_create(int device, void* stream, fv_ctx** out) {
     fv_ctx* c = new fv_ctx();
     c->device = device;
     c->stream = (hipStream_t)stream;
+    bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i)
+        ok = hipEventCreateWithFlags(&c->ev_dz[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_wg[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { delete c; return fv_fail(nullptr, FV_ERR_HIP, "fv_create: could not create the side stream / events"); }
     *out = c;
     return FV_OK;
 }

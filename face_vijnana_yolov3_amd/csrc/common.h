@@ -20,6 +20,11 @@ struct fv_ctx {
     bool prof_on = false;
     std::vector<FvProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
+    // backward-pass overlap: weight-gradient kernels run on a side stream next to the
+    // data-gradient / BN-backward chain (fv_set_overlap)
+    bool overlap = true;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr};
     ~fv_ctx();
 };
 

@@ -69,7 +69,7 @@ struct Carver {
 struct Plan {
     int B, S, nl;
     std::vector<float*> z, a, mean, invstd, scale, shift, wt;
-    float *psum, *psq, *pdb, *pdg, *w0p, *yhat, *dyp, *G[3], *loss;
+    float *psum, *psq, *pdb, *pdg, *w0p, *yhat, *dyp, *G[3], *D[2], *loss;
     size_t bytes;
 };
 
@@ -115,7 +115,8 @@ Plan make_plan(void* base, int B, int S, bool training) {
         p.psum = c.take(max_part); p.psq = c.take(max_part);
         p.pdb = c.take(max_bwd); p.pdg = c.take(max_bwd);
         p.dyp = c.take((size_t)B * G * G * HEAD_PAD);
-        for (int i = 0; i < 3; ++i) p.G[i] = c.take(max_act);
+        for (int i = 0; i < 2; ++i) p.G[i] = c.take(max_act);   // activation gradients (ping-pong + kept block gradient)
+        for (int i = 0; i < 2; ++i) p.D[i] = c.take(max_act);   // dz of layer l lives in D[l&1] until its wgrad has run
         p.loss = c.take(64);
     } else {
         for (int i = 0; i < 3; ++i) p.G[i] = c.take(max_act);
@@ -236,30 +237,57 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
     if (int rc = fv_op_conv_wgrad(ctx, p.a[nb - 1], p.dyp, batch, G, G, h.cin, h.cout, HEAD_PAD, 3, 1, grads + h.w_off)) return rc;
     if (int rc = fv_op_conv_dgrad(ctx, p.dyp, p.wt[nb], batch, G, G, h.cin, HEAD_PAD, 3, 1, nullptr, p.G[0])) return rc;
     if (on_bucket) on_bucket(user, h.w_off, (int64_t)HEAD_C * 9 * 1024 + HEAD_C);
-    // G[ig]: gradient w.r.t. the current layer's (post-add) output; G[ires]: kept block gradient
+    // G[ig]: gradient w.r.t. the current layer's (post-add) output; G[ires]: kept block gradient.
+    // dz(l) -> D[l&1].  The weight-gradient of layer l only needs dz(l) and the saved forward
+    // activation, so it runs on the side stream while this stream continues with dgrad(l) and
+    // bn_bwd(l-1); D[l&1] is reused by layer l-2 only after wgrad(l) has signalled ev_wg[l&1], which is
+    // also when the layer's gradient range is handed to the bucket callback.
+    const bool ov = ctx->overlap && ctx->side;
+    hipStream_t main_stream = ctx->stream;
+    struct Pending { bool on; int64_t off, cnt; } pend[2] = {{false, 0, 0}, {false, 0, 0}};
+    auto join = [&](int par) -> int {
+        if (!pend[par].on) return FV_OK;
+        FV_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_wg[par], 0));
+        if (on_bucket) on_bucket(user, pend[par].off, pend[par].cnt);
+        pend[par].on = false;
+        return FV_OK;
+    };
     int ig = 0, ires = -1;
     for (int l = nb - 1; l >= 0; --l) {
         const auto& d = N.L[l];
         const int H = S / d.in_div, Ho = S / d.out_div;
         const long long rows = (long long)batch * Ho * Ho;
-        int idz = 0;
-        while (idz == ig || idz == ires) ++idz;
-        float* dz = p.G[idz];
+        const int par = l & 1;
+        if (int rc = join(par)) return rc;
+        float* dz = p.D[par];
         if (d.role == 2) ires = ig;  // add(skip, x): the same gradient also reaches the skip input
         if (int rc = fv_ew_bn_bwd(ctx, p.G[ig], p.z[l], p.scale[l], p.shift[l], p.mean[l], p.invstd[l], rows, d.cout, LEAKY,
                                   p.pdb, p.pdg, grads + d.beta_off, grads + d.gamma_off, dz)) return rc;
         const float* xin = l == 0 ? x : p.a[l - 1];
-        if (int rc = fv_op_conv_wgrad(ctx, xin, dz, batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off)) return rc;
-        if (on_bucket) on_bucket(user, d.w_off, (int64_t)d.cout * d.ksize * d.ksize * d.cin + 2 * d.cout);
+        const int64_t cnt = (int64_t)d.cout * d.ksize * d.ksize * d.cin + 2 * d.cout;
+        if (ov) {
+            FV_HIP(ctx, hipEventRecord(ctx->ev_dz[par], main_stream));
+            FV_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_dz[par], 0));
+            ctx->stream = ctx->side;
+            int rc = fv_op_conv_wgrad(ctx, xin, dz, batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off);
+            ctx->stream = main_stream;
+            if (rc) return rc;
+            FV_HIP(ctx, hipEventRecord(ctx->ev_wg[par], ctx->side));
+            pend[par] = Pending{true, d.w_off, cnt};
+        } else {
+            if (int rc = fv_op_conv_wgrad(ctx, xin, dz, batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off)) return rc;
+            if (on_bucket) on_bucket(user, d.w_off, cnt);
+        }
         if (l == 0) break;
-        // dgrad writes over the consumed gradient buffer G[ig] (bn_bwd has read it), unless that
-        // buffer is the kept block gradient
-        int iout = (ig == ires) ? 3 - idz - ig : ig;
+        // dgrad overwrites the consumed gradient buffer G[ig] unless that is the kept block gradient
+        const int iout = (ig == ires) ? 1 - ig : ig;
         const float* addend = d.role == 1 ? p.G[ires] : nullptr;
         if (int rc = fv_op_conv_dgrad(ctx, dz, p.wt[l], batch, H, H, d.cin, d.cout, d.ksize, d.stride, addend, p.G[iout])) return rc;
         ig = iout;
         if (d.role == 1) ires = -1;
     }
+    if (int rc = join(1)) return rc;   // layer 1, then layer 0: ranges stay in descending order
+    if (int rc = join(0)) return rc;
     return FV_OK;
 }
 

@@ -42,6 +42,12 @@ int fv_create(int device, void* stream, fv_ctx** out);
 void fv_destroy(fv_ctx* ctx);
 const char* fv_last_error(const fv_ctx* ctx);
 int fv_set_stream(fv_ctx* ctx, void* stream);
+/* fv_train_step runs the weight-gradient kernels on an internal side stream, concurrently with the
+ * data-gradient / BN-backward chain on the context's stream (they are independent given dz); all
+ * side-stream work is joined back into the context's stream before fv_train_step returns control
+ * of a gradient range (fv_bucket_fn) and before it returns.  on = 0 serialises everything on the
+ * context's stream (default: on). */
+int fv_set_overlap(fv_ctx* ctx, int on);
 
 /* ------------------------------------------------------------------ per-kernel timing
  * Measurement aid with no counterpart in the reference (it has no profiler hooks):

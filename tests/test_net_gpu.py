@@ -151,3 +151,23 @@ def test_bucketed_side_stream_path_equals_plain(eng):
     assert abs(outs[0][0] - outs[1][0]) <= 1e-4 * abs(outs[0][0])
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=0, atol=5e-4)   # 2 Adam steps of lr 1e-4: |dp| <= 2e-4
     torch.testing.assert_close(outs[0][2], outs[1][2], rtol=1e-4, atol=1e-5)
+
+
+def test_side_stream_overlap_equals_serial(eng):
+    """fv_set_overlap: wgrad on the side stream vs everything on one stream -- same gradients (up to
+    the float-atomic summation order inside dW), same bucket protocol."""
+    p64, s64, x, yt = _setup(13, 4, 96)
+    res = []
+    for on in (True, False):
+        eng.ctx.set_overlap(on)
+        eng.set_params(p64.float(), s64.float())
+        eng.m = eng.v = eng.grads = None
+        buckets = []
+        loss = eng.forward_backward(x.float(), yt.float(), on_bucket=lambda o, c: buckets.append((o, c)))
+        torch.cuda.synchronize()
+        res.append((loss.item(), eng.grads.clone(), list(buckets)))
+    eng.ctx.set_overlap(True)
+    assert res[0][0] == res[1][0]
+    assert res[0][2] == res[1][2]
+    d = (res[0][1] - res[1][1]).abs().max().item()
+    assert d <= 1e-5 * res[1][1].abs().max().item() + 1e-9, d
