@@ -66,6 +66,44 @@ def cpu_baseline(batch, image_size):
                        % (batch, image_size, image_size, dt))
 
 
+def detect_bench(eng, x40):
+    """BASELINE metric 2, detect-path ms/img (fd.py:885-949 = predict + decode/NMS/top-k):
+    batch 1 as the reference's evaluate loop calls it, batch 40, and config 4 (post-processing alone
+    on 10k synthetic head outputs).  Device-side times (stream-ordered, one sync at the end)."""
+    import numpy as np
+    import torch
+    from face_vijnana_yolov3_amd.postproc import decode_nms, to_boundboxes
+
+    def timed(fn, reps):
+        fn(); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    x1 = x40[:1].contiguous()
+    S = x40.shape[1]
+    one = lambda xb: decode_nms(eng.ctx, eng.predict_device(xb), S, 0.5, 0.5, 60)
+    t1 = timed(lambda: one(x1), 20)
+    t40 = timed(lambda: one(x40), 5)
+    import time as _t
+    t0 = _t.perf_counter()
+    for _ in range(20):
+        to_boundboxes(one(x1), 0)           # end to end incl. D2H + BoundBox objects, as detect() returns
+    e2e = (_t.perf_counter() - t0) / 20 * 1e3
+    rng = np.random.default_rng(99)
+    head = np.zeros((10000, 13, 13, 6), np.float32)
+    head[..., 0] = rng.normal(0, 2, (10000, 13, 13)); head[..., 5] = rng.normal(0, 2, (10000, 13, 13))
+    head[..., 1:3] = rng.uniform(0, 1, (10000, 13, 13, 2)); head[..., 3:5] = rng.uniform(0, 0.3, (10000, 13, 13, 2))
+    hd = torch.from_numpy(head).cuda()
+    tpp = timed(lambda: decode_nms(eng.ctx, hd, 416, 0.5, 0.5, 60), 10)
+    return dict(unit='ms/img', batch1_device=round(t1, 4), batch1_end_to_end=round(e2e, 4),
+                batch40_device=round(t40 / x40.shape[0], 4), postproc_10k_frames=round(tpp / 10000, 6),
+                postproc_10k_total_ms=round(tpp, 3))
+
+
 def main():
     args = parse()
     import torch
@@ -111,19 +149,30 @@ def main():
     out = None
     if rank == 0:
         # instrumented steps for the roofline of the dominant kernel (HIP events on the launch stream)
-        prof = {}
+        # They run with fv_set_overlap(0): under the backward overlap two MFMA kernels time-share the
+        # chip and a launch's elapsed time is no longer that kernel's own rate (the timed region
+        # above keeps the overlap; `roofline_overlapped` repeats the measurement with it on).
+        prof, prof_ov = {}, {}
         if args.profile_steps > 0:
-            eng.ctx.profile(True)
-            for _ in range(args.profile_steps):
-                step()
-            prof = eng.ctx.profile_collect()
-            eng.ctx.profile(False)
+            for on, store in ((False, prof), (True, prof_ov)):
+                if args.no_overlap and on:
+                    continue
+                eng.ctx.set_overlap(on)
+                step(); torch.cuda.synchronize()
+                eng.ctx.profile(True)
+                for _ in range(args.profile_steps):
+                    step()
+                store.update(eng.ctx.profile_collect())
+                eng.ctx.profile(False)
+            eng.ctx.set_overlap(not args.no_overlap)
+        detect = detect_bench(eng, x)
         dom = prof.get(DOMINANT)
         roofline = None
         if dom and dom['ms'] > 0:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
             roofline = dict(bound='mfma', achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                             frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None, kernel=DOMINANT,
+                            mode='exclusive: instrumented steps run with fv_set_overlap(0)',
                             launches_per_step=dom['launches'] // max(args.profile_steps, 1),
                             avg_launch_ms=round(dom['ms'] / dom['launches'], 4),
                             gflop_per_launch=round(dom['flops'] / dom['launches'] / 1e9, 3))
@@ -146,7 +195,11 @@ def main():
                        'global_batch': world * B, 'parallelism': 'dp%d' % world},
             'loss': loss_v,
             'step_tflops_per_gpu': round(train_flops * B * args.steps / dt / 1e12, 2),
+            'step_frac_of_fp32_mfma_peak': round(train_flops * B * args.steps / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
             'roofline': roofline,
+            'roofline_overlapped': (lambda d: None if not d or not d['ms'] else dict(
+                achieved=round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2), avg_launch_ms=round(d['ms'] / d['launches'], 4)))(prof_ov.get(DOMINANT)),
+            'detect': detect,
             'kernels': kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
