@@ -36,12 +36,16 @@ struct FvConvArgs {
     float leaky;
     int nclass;   // 1, or 4 for stride-2 data-gradient
     double alg_flops;  // algorithmic 2*MAC of this launch (profiling only)
+    int ksplit;        // >1: blockIdx.y owns a slice of the K steps and stores its raw partial to out + y*split_stride
+    long long split_stride;
     int oph[4], opw[4];
     FvTaps taps[4];
 };
 
 // Number of M tiles (rows of psum/psq) the conv launch will use for this problem.
 int fv_conv_mtiles(int M, int Nout);
+// K-split factor the small-M inference path uses for a problem (1 = no split).
+int fv_conv_choose_ksplit(int M, int Nout, int ksteps);
 int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a);
 
 // Weight gradient:  dw[n][wslot[t]][c] += sum_{b,oh,ow} dy[b,oh,ow,n] * x[b, oh*is+dh[t], ow*is+dw[t], c]

@@ -156,9 +156,13 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
 
         const int cpk = a.Cin / BK;
         const int nk = taps.n * cpk;
+        // split-K (small-M inference): this block owns K steps [s_begin, s_end)
+        const int per = (nk + a.ksplit - 1) / a.ksplit;
+        const int s_begin = blockIdx.y * per;
+        const int s_end = min(nk, s_begin + per);
         u32x4 ra[4], rb[BL];
         unsigned a_off[4];
-        int t = 0, ci = 0;
+        int t = s_begin / cpk, ci = s_begin - t * cpk;
         auto set_tap = [&](int tp) {
             const int dh = taps.dh[tp], dw = taps.dw[tp];
 #pragma unroll
@@ -209,14 +213,16 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
                 }
         };
 
-        set_tap(0);
-        load();
-        stage(0);
-        advance();
+        if (s_begin < s_end) {
+            set_tap(t);
+            load();
+            stage(0);
+            advance();
+        }
         __syncthreads();
-        for (int s = 0; s < nk; ++s) {
-            const int cur = s & 1;
-            const bool more = s + 1 < nk;
+        for (int s = s_begin; s < s_end; ++s) {
+            const int cur = (s - s_begin) & 1;
+            const bool more = s + 1 < s_end;
             if (more) load();
             float4 af0[MB], bf0[NB], af1[MB], bf1[NB];
             readfrag(As[cur], Bs[cur], 0, af0, bf0);
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
                     if (a.epi & FV_EPI_AFFINE) v = v * sc + sh;
                     if (a.epi & FV_EPI_LEAKY) v = v > 0.0f ? v : v * a.leaky;
                     if (a.epi & FV_EPI_ADD) v += a.addend[off + n];
-                    a.out[off + n] = v;
+                    a.out[(size_t)blockIdx.y * a.split_stride + off + n] = v;
                 }
             }
     }
@@ -284,14 +290,16 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
 template <int BN, int WM_, int WN_, bool G>
 int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
     const int MT = (a.M + BM - 1) / BM, NT = (a.Nout + BN - 1) / BN;
-    dim3 grid(MT * NT, 1, a.nclass);
+    dim3 grid(MT * NT, a.ksplit > 1 ? a.ksplit : 1, a.nclass);
     static const char* name = BN == 128 ? (G ? "conv_kernel<128,2,2,true>" : "conv_kernel<128,2,2,false>")
                               : BN == 64 ? (G ? "conv_kernel<64,2,2,true>" : "conv_kernel<64,2,2,false>")
                                          : (G ? "conv_kernel<32,4,1,true>" : "conv_kernel<32,4,1,false>");
     FvProfScope ps(ctx, name, a.alg_flops,
                    4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.Nout * a.Tw * a.Cin +
                           (double)a.M * a.nclass * a.Nout * ((a.epi & FV_EPI_ADD) ? 2 : 1)));
-    hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G>), grid, dim3(256), 0, ctx->stream, a);
+    FvConvArgs b = a;
+    if (b.ksplit < 1) b.ksplit = 1;
+    hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G>), grid, dim3(256), 0, ctx->stream, b);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }
@@ -299,6 +307,15 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
 }  // namespace
 
 int fv_conv_mtiles(int M, int Nout) { (void)Nout; return (M + BM - 1) / BM; }
+
+int fv_conv_choose_ksplit(int M, int Nout, int ksteps) {
+    const int bn = Nout > 64 ? 128 : (Nout > 32 ? 64 : 32);
+    const int tiles = ((M + BM - 1) / BM) * ((Nout + bn - 1) / bn);
+    if (tiles >= 192 || ksteps < 8) return 1;         // enough tiles to fill 256 CUs, or nothing to split
+    int want = (512 + tiles - 1) / tiles, cap = ksteps / 4;
+    int ks = want < cap ? want : cap;
+    return ks < 1 ? 1 : ks;
+}
 
 int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
     FV_REQUIRE(ctx, a.x && a.w && a.out, "conv: NULL tensor");
@@ -309,6 +326,7 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
                "conv: input/weight tensor exceeds 2^29 elements (2 GiB buffer descriptor) or output 2^31");
     FV_REQUIRE(ctx, !(a.epi & FV_EPI_STATS) || (a.psum && a.psq && a.nclass == 1), "conv: stats need psum/psq");
     FV_REQUIRE(ctx, !(a.epi & FV_EPI_ADD) || a.addend, "conv: FV_EPI_ADD needs addend");
+    FV_REQUIRE(ctx, a.ksplit <= 1 || (a.epi == 0 && a.nclass == 1 && a.Cin % BK == 0), "conv: split-K stores raw partials only");
     const bool gather = a.Cin % BK != 0;
     if (gather) {
         FV_REQUIRE(ctx, 9 * a.Cin <= BK && a.nclass == 1 && a.is == 1 && a.os == 1 && a.taps[0].n == 9 &&

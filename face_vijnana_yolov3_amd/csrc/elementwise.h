@@ -18,3 +18,5 @@ int fv_ew_adam(fv_ctx* ctx, float* p, const float* g, float* m, float* v, long l
 int fv_ew_transpose_ntc(fv_ctx* ctx, const float* src, float* dst, int N, int T, int C, int Npad);
 int fv_ew_pad_rows(fv_ctx* ctx, const float* src, float* dst, int N, int K, int Kpad);
 int fv_ew_slice_cols(fv_ctx* ctx, const float* src, float* dst, long long rows, int C, int Cpad);
+int fv_ew_splitk_finish(fv_ctx* ctx, const float* slabs, int ksplit, long long stride, const float* scale, const float* shift,
+                        const float* skip, float* out, long long n, int C, float leaky, int do_leaky);

@@ -247,6 +247,23 @@ __global__ void slice_cols_kernel(const float* __restrict__ src, float* __restri
     if (i < rows * C) { long long r = i / C; int c = (int)(i - r * C); dst[i] = src[r * Cpad + c]; }
 }
 
+// out = leaky(scale * (sum over K-split partial slabs, fixed order) + shift) (+ skip); any C
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slabs, int ksplit, long long stride,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ skip, float* __restrict__ out, long long n,
+                                                            int C, float leaky, int do_leaky) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int k = 0; k < ksplit; ++k) v += slabs[k * stride + i];
+        const int c = (int)(i % C);
+        if (scale) v *= scale[c];
+        if (shift) v += shift[c];
+        if (do_leaky) v = v > 0.f ? v : v * leaky;
+        if (skip) v += skip[i];
+        out[i] = v;
+    }
+}
+
 inline int grid_for(long long n, int block, int cap = 256 * 8) {
     long long g = (n + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -350,6 +367,15 @@ int fv_ew_pad_rows(fv_ctx* ctx, const float* src, float* dst, int N, int K, int 
 
 int fv_ew_slice_cols(fv_ctx* ctx, const float* src, float* dst, long long rows, int C, int Cpad) {
     hipLaunchKernelGGL(slice_cols_kernel, dim3((unsigned)((rows * C + 255) / 256)), dim3(256), 0, ctx->stream, src, dst, rows, C, Cpad);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_ew_splitk_finish(fv_ctx* ctx, const float* slabs, int ksplit, long long stride, const float* scale, const float* shift,
+                        const float* skip, float* out, long long n, int C, float leaky, int do_leaky) {
+    FvProfScope ps(ctx, "splitk_finish_kernel", 0.0, 4.0 * n * (ksplit + 1 + (skip ? 1 : 0)));
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, slabs, ksplit, stride, scale, shift,
+                       skip, out, n, C, leaky, do_leaky);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }

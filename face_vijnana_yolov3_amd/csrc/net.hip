@@ -69,7 +69,7 @@ struct Carver {
 struct Plan {
     int B, S, nl;
     std::vector<float*> z, a, mean, invstd, scale, shift, wt;
-    float *psum, *psq, *pdb, *pdg, *w0p, *yhat, *dyp, *G[3], *D[2], *loss;
+    float *psum, *psq, *pdb, *pdg, *w0p, *yhat, *dyp, *G[3], *D[2], *loss, *slab;
     size_t bytes;
 };
 
@@ -120,6 +120,15 @@ Plan make_plan(void* base, int B, int S, bool training) {
         p.loss = c.take(64);
     } else {
         for (int i = 0; i < 3; ++i) p.G[i] = c.take(max_act);
+        // K-split partial slabs of the small-M layers (batch-1 latency path)
+        size_t max_slab = 0;
+        for (int l = 1; l < p.nl; ++l) {
+            const auto& d = N.L[l];
+            size_t rows = (size_t)B * (S / d.out_div) * (S / d.out_div);
+            int ks = fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32);
+            if (ks > 1 && ks * rows * d.cout > max_slab) max_slab = ks * rows * d.cout;
+        }
+        p.slab = max_slab ? c.take(max_slab) : nullptr;
     }
     p.bytes = c.off;
     return p;
@@ -176,14 +185,32 @@ int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, co
         while (iout == icur || (iout == iskip && (d.role == 1 || d.role == 2))) ++iout;
         float* out = p.G[iout];
         const float* w = l == 0 ? p.w0p : params + d.w_off;
-        int epi = FV_EPI_AFFINE | FV_EPI_LEAKY | (d.role == 2 ? FV_EPI_ADD : 0);
-        if (int rc = fv_op_conv_forward(ctx, cur, w, batch, H, H, d.cin, d.cout, d.ksize, d.stride, epi, p.scale[l], p.shift[l],
-                                        LEAKY, d.role == 2 ? skip : nullptr, out, nullptr, nullptr)) return rc;
+        const long long rows = (long long)batch * (H / d.stride) * (H / d.stride);
+        const int ks = l == 0 ? 1 : fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32);
+        if (ks > 1) {
+            // small M (batch-1 latency): K-split partial slabs, summed in fixed order by the finish kernel
+            if (int rc = fv_op_conv_forward(ctx, cur, w, batch, H, H, d.cin, d.cout, d.ksize, d.stride, 0, nullptr, nullptr, 0.f,
+                                            nullptr, p.slab, nullptr, nullptr, ks)) return rc;
+            if (int rc = fv_ew_splitk_finish(ctx, p.slab, ks, rows * d.cout, p.scale[l], p.shift[l], d.role == 2 ? skip : nullptr,
+                                             out, rows * d.cout, d.cout, LEAKY, 1)) return rc;
+        } else {
+            int epi = FV_EPI_AFFINE | FV_EPI_LEAKY | (d.role == 2 ? FV_EPI_ADD : 0);
+            if (int rc = fv_op_conv_forward(ctx, cur, w, batch, H, H, d.cin, d.cout, d.ksize, d.stride, epi, p.scale[l], p.shift[l],
+                                            LEAKY, d.role == 2 ? skip : nullptr, out, nullptr, nullptr)) return rc;
+        }
         cur = out; icur = iout;
         if (d.role == 2) { skip = nullptr; iskip = -1; }
     }
     const auto& h = N.L[nb];
     const int G = image_size / h.in_div;
+    const long long hrows = (long long)batch * G * G;
+    const int hks = fv_conv_choose_ksplit((int)hrows, h.cout, 9 * h.cin / 32);
+    if (hks > 1) {
+        if (int rc = fv_op_conv_forward(ctx, cur, params + h.w_off, batch, G, G, h.cin, h.cout, 3, 1, 0, nullptr, nullptr, 0.f,
+                                        nullptr, p.slab, nullptr, nullptr, hks)) return rc;
+        return fv_ew_splitk_finish(ctx, p.slab, hks, hrows * h.cout, nullptr, params + h.beta_off, nullptr, y, hrows * h.cout,
+                                   h.cout, 0.f, 0);
+    }
     return fv_op_conv_forward(ctx, cur, params + h.w_off, batch, G, G, h.cin, h.cout, 3, 1, FV_EPI_AFFINE, nullptr,
                               params + h.beta_off, 0.f, nullptr, y, nullptr, nullptr);
 }
