@@ -83,6 +83,7 @@ def _declare(L):
         'fv_bn_bwd_scratch_floats': (i64, [i64, i32]),
         'fv_bn_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp, vp, vp, vp]),
         'fv_mse_loss_grad': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+        'fv_fd_loss_grad': (i32, [vp, vp, vp, i32, i32, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -20,3 +20,7 @@ int fv_ew_pad_rows(fv_ctx* ctx, const float* src, float* dst, int N, int K, int 
 int fv_ew_slice_cols(fv_ctx* ctx, const float* src, float* dst, long long rows, int C, int Cpad);
 int fv_ew_splitk_finish(fv_ctx* ctx, const float* slabs, int ksplit, long long stride, const float* scale, const float* shift,
                         const float* skip, float* out, long long n, int C, float leaky, int do_leaky);
+int fv_ew_bn_fold_all(fv_ctx* ctx, const float* params, const float* state, int nlayers, const int* ch_begin, const long long* gamma_off,
+                      const long long* beta_off, const long long* mean_off, const long long* var_off, float eps, int total,
+                      float* scale, float* shift);
+int fv_ew_fd_loss(fv_ctx* ctx, const float* yp, const float* yt, int cells, int Cpad, float* loss, float* dy);

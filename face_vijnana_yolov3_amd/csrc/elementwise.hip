@@ -58,6 +58,20 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
     }
 }
 
+// all BN layers at once: thread = one channel of the whole network (channel offsets are mean_off/2)
+struct FoldTable { int n; int ch_begin[64]; int gamma_off[64]; int beta_off[64]; int mean_off[64]; int var_off[64]; };
+__global__ void bn_fold_all_kernel(const float* __restrict__ params, const float* __restrict__ state, FoldTable t, float eps,
+                                   int total, float* __restrict__ scale, float* __restrict__ shift) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    int lo = 0, hi = t.n - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (t.ch_begin[mid] <= g) lo = mid; else hi = mid - 1; }
+    const int c = g - t.ch_begin[lo];
+    float sc = params[t.gamma_off[lo] + c] / sqrtf(state[t.var_off[lo] + c] + eps);
+    scale[g] = sc;
+    shift[g] = params[t.beta_off[lo] + c] - state[t.mean_off[lo] + c] * sc;
+}
+
 // ---------------------------------------------------------------- y = leaky(z*scale+shift) (+ skip)
 __global__ __launch_bounds__(256) void bn_act_kernel(const float4* __restrict__ z, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, const float4* __restrict__ skip,
@@ -188,6 +202,44 @@ __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ yp,
         __syncthreads();
         if (rl == 0 && cl < C) { for (int k = 1; k < 32; ++k) s += scol[k * 32 + cl]; dbias[cl] = (float)s; }
     }
+}
+
+// ---------------------------------------------------------------- fd_loss (reference fd.py:59-64; defined there, never used)
+// per cell: (BCE(y0,p0) + mean_{1..4} sqrt((y-p)^2) + BCE(y5,p5)) / 3 with Keras' probability-space BCE
+// (p clipped to [1e-7, 1-1e-7]); loss = mean over cells.  Gradient: (p-y)/(p(1-p)) inside the clip range, 0 outside;
+// -sign(y-p)/4 for the box terms (0 at equality, where TF's sqrt gradient is nan).  Single block, deterministic.
+__global__ __launch_bounds__(1024) void fd_loss_kernel(const float* __restrict__ yp, const float* __restrict__ yt, int cells, int Cpad,
+                                                       float* __restrict__ loss, float* __restrict__ dy) {
+    __shared__ double sred[1024];
+    const double eps = 1e-7;
+    const double gs = 1.0 / (3.0 * (double)cells);
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < cells; i += 1024) {
+        const float* p = yp + (size_t)i * 6;
+        const float* t = yt + (size_t)i * 6;
+        float* g = dy + (size_t)i * Cpad;
+        double cell = 0.0;
+        for (int k = 0; k < 6; k += 5) {
+            double raw = (double)p[k], y = (double)t[k];
+            double pc = raw < eps ? eps : (raw > 1.0 - eps ? 1.0 - eps : raw);
+            cell += -(y * log(pc) + (1.0 - y) * log1p(-pc));
+            bool inside = raw >= eps && raw <= 1.0 - eps;
+            g[k] = inside ? (float)(gs * (pc - y) / (pc * (1.0 - pc))) : 0.0f;
+        }
+        double l1 = 0.0;
+        for (int k = 1; k < 5; ++k) {
+            double d = (double)t[k] - (double)p[k];
+            l1 += fabs(d);
+            g[k] = (float)(gs * 0.25 * (d > 0.0 ? -1.0 : (d < 0.0 ? 1.0 : 0.0)));
+        }
+        cell += 0.25 * l1;
+        for (int k = 6; k < Cpad; ++k) g[k] = 0.0f;
+        acc += cell / 3.0;
+    }
+    sred[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) { if (threadIdx.x < s) sred[threadIdx.x] += sred[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) *loss = (float)(sred[0] / (double)cells);
 }
 
 // ---------------------------------------------------------------- Adam (Keras 2.2.4 formula)
@@ -376,6 +428,28 @@ int fv_ew_splitk_finish(fv_ctx* ctx, const float* slabs, int ksplit, long long s
     FvProfScope ps(ctx, "splitk_finish_kernel", 0.0, 4.0 * n * (ksplit + 1 + (skip ? 1 : 0)));
     hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, slabs, ksplit, stride, scale, shift,
                        skip, out, n, C, leaky, do_leaky);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_ew_bn_fold_all(fv_ctx* ctx, const float* params, const float* state, int nlayers, const int* ch_begin, const long long* gamma_off,
+                      const long long* beta_off, const long long* mean_off, const long long* var_off, float eps, int total,
+                      float* scale, float* shift) {
+    FV_REQUIRE(ctx, nlayers <= 64, "bn_fold_all: too many layers");
+    FoldTable t{};
+    t.n = nlayers;
+    for (int i = 0; i < nlayers; ++i) {
+        t.ch_begin[i] = ch_begin[i]; t.gamma_off[i] = (int)gamma_off[i]; t.beta_off[i] = (int)beta_off[i];
+        t.mean_off[i] = (int)mean_off[i]; t.var_off[i] = (int)var_off[i];
+    }
+    hipLaunchKernelGGL(bn_fold_all_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, params, state, t, eps, total, scale, shift);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_ew_fd_loss(fv_ctx* ctx, const float* yp, const float* yt, int cells, int Cpad, float* loss, float* dy) {
+    FV_REQUIRE(ctx, Cpad >= 6, "fd_loss: Cpad must be >= 6");
+    hipLaunchKernelGGL(fd_loss_kernel, dim3(1), dim3(1024), 0, ctx->stream, yp, yt, cells, Cpad, loss, dy);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }

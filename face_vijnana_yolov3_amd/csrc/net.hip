@@ -93,10 +93,15 @@ Plan make_plan(void* base, int B, int S, bool training) {
         size_t bw = (size_t)fv_ew_bn_bwd_chunks((long long)rows, d.cout) * d.cout;
         if (bw > max_bwd) max_bwd = bw;
     }
-    for (int l = 0; l < nb; ++l) {
-        const auto& d = N.L[l];
-        p.scale[l] = c.take(d.cout); p.shift[l] = c.take(d.cout);
-        if (training) { p.mean[l] = c.take(d.cout); p.invstd[l] = c.take(d.cout); }
+    {   // per-channel BN vectors of all layers are contiguous (channel offset = mean_off / 2)
+        float* sc_all = c.take((size_t)N.nstate / 2);
+        float* sh_all = c.take((size_t)N.nstate / 2);
+        for (int l = 0; l < nb; ++l) {
+            const auto& d = N.L[l];
+            p.scale[l] = sc_all ? sc_all + d.mean_off / 2 : nullptr;
+            p.shift[l] = sh_all ? sh_all + d.mean_off / 2 : nullptr;
+            if (training) { p.mean[l] = c.take(d.cout); p.invstd[l] = c.take(d.cout); }
+        }
     }
     p.w0p = c.take(32 * 32);
     const int G = S / 32;
@@ -167,10 +172,13 @@ int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, co
     if (p.bytes > workspace_bytes) return fv_fail(ctx, FV_ERR_WORKSPACE, "forward_infer: workspace %zu < %zu bytes", workspace_bytes, p.bytes);
     const Net& N = net();
     const int nb = p.nl - 1;
-    for (int l = 0; l < nb; ++l) {
-        const auto& d = N.L[l];
-        if (int rc = fv_ew_bn_fold(ctx, params + d.gamma_off, params + d.beta_off, bn_state + d.mean_off, bn_state + d.var_off,
-                                   BN_EPS, d.cout, p.scale[l], p.shift[l])) return rc;
+    {   // fold the moving statistics of all 52 BN layers into scale/shift with one launch
+        int chb[64]; long long go[64], bo[64], mo[64], vo[64];
+        for (int l = 0; l < nb; ++l) {
+            const auto& d = N.L[l];
+            chb[l] = (int)(d.mean_off / 2); go[l] = d.gamma_off; bo[l] = d.beta_off; mo[l] = d.mean_off; vo[l] = d.var_off;
+        }
+        if (int rc = fv_ew_bn_fold_all(ctx, params, bn_state, nb, chb, go, bo, mo, vo, BN_EPS, (int)(N.nstate / 2), p.scale[0], p.shift[0])) return rc;
     }
     if (int rc = fv_ew_pad_rows(ctx, params + N.L[0].w_off, p.w0p, 32, 27, 32)) return rc;
     // rotating buffers: cur (input), skip (kept while a residual block runs), out

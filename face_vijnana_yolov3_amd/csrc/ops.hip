@@ -162,6 +162,11 @@ int fv_mse_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int rows, in
     return fv_ew_mse(ctx, yp, yt, rows, C, c_pad, loss, dy, dbias);
 }
 
+int fv_fd_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int cells, int c_pad, float* loss, float* dy) {
+    if (!ctx) return FV_ERR_INVALID;
+    return fv_ew_fd_loss(ctx, yp, yt, cells, c_pad, loss, dy);
+}
+
 int fv_adam_step(fv_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n, int64_t iteration, double lr,
                  double beta_1, double beta_2, double eps, double decay) {
     if (!ctx) return FV_ERR_INVALID;

@@ -109,6 +109,15 @@ def mse_loss_grad(ctx, yp, yt, c_pad=32):
     return loss, dy, db
 
 
+def fd_loss_grad(ctx, yp, yt, c_pad=32):
+    """The reference's unused fd_loss (face_detection.py:59-64) and its gradient."""
+    cells = yp.numel() // 6
+    loss = torch.empty(1, dtype=torch.float32, device=yp.device)
+    dy = torch.empty((cells, c_pad), dtype=torch.float32, device=yp.device)
+    ctx.check(lib().fv_fd_loss_grad(ctx.handle, ptr(yp.contiguous()), ptr(yt.contiguous()), cells, c_pad, ptr(loss), ptr(dy)), 'fv_fd_loss_grad')
+    return loss, dy
+
+
 def adam_step(ctx, p, g, m, v, iteration, lr, beta_1, beta_2, eps=1e-7, decay=0.0):
     rc = lib().fv_adam_step(ctx.handle, ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), int(iteration), float(lr), float(beta_1),
                             float(beta_2), float(eps), float(decay))

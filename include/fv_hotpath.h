@@ -171,6 +171,13 @@ int fv_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale, c
  * dbias[C] = column sums of dy (may be NULL). */
 int fv_mse_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int c_pad,
                      float* loss, float* dy, float* dbias);
+/* fd_loss (fd.py:59-64) -- DEFINED BUT NEVER USED by the reference (every compile() passes
+ * loss='mse', fd.py:335/366/370/381); provided as an operator only, not wired into fv_train_step.
+ * yp, yt [cells][6]; per cell (BCE(y0,p0) + mean_{c=1..4} sqrt((y_c-p_c)^2) + BCE(y5,p5))/3 with
+ * Keras' probability-space binary_crossentropy (p clipped to [1e-7, 1-1e-7]); loss = mean over
+ * cells; dy [cells][c_pad] its gradient (0 outside the clip range and at y_c == p_c). */
+int fv_fd_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int cells, int c_pad, float* loss,
+                    float* dy);
 
 #ifdef __cplusplus
 }

@@ -147,6 +147,18 @@ def mse(y_pred, y_true):
     return ((y_pred - y_true) ** 2).mean()
 
 
+def fd_loss(y_pred, y_true, eps=1e-7):
+    """The reference's fd_loss (face_detection.py:59-64; defined, never used) with Keras 2.2.4
+    K.binary_crossentropy on probabilities (clip to [eps, 1-eps]); returns the mean over cells."""
+    def bce(t, o):
+        o = torch.clamp(o, eps, 1.0 - eps)
+        return -(t * torch.log(o) + (1.0 - t) * torch.log1p(-o))
+    o_loss = bce(y_true[..., 0], y_pred[..., 0])
+    l2_loss = torch.mean(torch.abs(y_true[..., 1:5] - y_pred[..., 1:5]), dim=-1)
+    c_loss = bce(y_true[..., 5], y_pred[..., 5])
+    return ((o_loss + l2_loss + c_loss) / 3.0).mean()
+
+
 def train_step_grads(params, state, x, y_true):
     """One fwd + mse + bwd: -> (loss, grads flat, new_state)."""
     p = params.clone().requires_grad_(True)

@@ -203,3 +203,18 @@ def test_adam_matches_keras_formula(ctx):
     torch.testing.assert_close(pd.cpu().double(), rp, rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(md.cpu().double(), rm, rtol=1e-5, atol=1e-10)
     torch.testing.assert_close(vd.cpu().double(), rv, rtol=1e-5, atol=1e-12)
+
+
+def test_fd_loss_and_grad(ctx):
+    """fd_loss is defined but unused in the reference (fd.py:59-64); operator-level parity only."""
+    from face_vijnana_yolov3_amd import ops
+    from oracle import net_oracle as no
+    yp = _rand((3 * 169, 6), 61, -0.3, 1.3)          # linear head: values outside [0,1] get clipped
+    yt = (_rand((3 * 169, 6), 62, 0, 1) > 0.7).float(); yt[:, 1:5] = _rand((3 * 169, 4), 63, 0, 1)
+    ypd = yp.double().clone().requires_grad_(True)
+    ref = no.fd_loss(ypd, yt.double())
+    (rg,) = torch.autograd.grad(ref, ypd)
+    loss, dy = ops.fd_loss_grad(ctx, yp.cuda(), yt.cuda(), 32)
+    assert abs(loss.item() - ref.item()) <= 2e-6 * abs(ref.item())
+    torch.testing.assert_close(dy.cpu()[:, :6].double(), rg, rtol=2e-6, atol=1e-9)
+    assert torch.count_nonzero(dy[:, 6:]) == 0
