@@ -110,6 +110,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'FV_BENCH_DEVICE' in os.environ:   # rehearsal aid: several ranks on one GPU (not a measurement)
+        local_rank = int(os.environ['FV_BENCH_DEVICE'])
     if world != args.gpus and world > 1:
         raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
     if args.gpus > 1 and world == 1:
@@ -146,25 +148,29 @@ def main():
     dt = trainer.max_over_ranks(dt)
     loss_v = float(loss.item())
 
-    out = None
-    if rank == 0:
-        # instrumented steps for the roofline of the dominant kernel (HIP events on the launch stream)
-        # They run with fv_set_overlap(0): under the backward overlap two MFMA kernels time-share the
-        # chip and a launch's elapsed time is no longer that kernel's own rate (the timed region
-        # above keeps the overlap; `roofline_overlapped` repeats the measurement with it on).
-        prof, prof_ov = {}, {}
-        if args.profile_steps > 0:
-            for on, store in ((False, prof), (True, prof_ov)):
-                if args.no_overlap and on:
-                    continue
-                eng.ctx.set_overlap(on)
-                step(); torch.cuda.synchronize()
+    # instrumented steps for the roofline of the dominant kernel (HIP events on the launch stream).
+    # They run with fv_set_overlap(0): under the backward overlap two MFMA kernels time-share the
+    # chip and a launch's elapsed time is no longer that kernel's own rate (the timed region above
+    # keeps the overlap; `roofline_overlapped` repeats the measurement with it on).  EVERY rank runs
+    # these steps (they contain the gradient collectives); only rank 0 records events.
+    prof, prof_ov = {}, {}
+    if args.profile_steps > 0:
+        for on, store in ((False, prof), (True, prof_ov)):
+            if args.no_overlap and on:
+                continue
+            eng.ctx.set_overlap(on)
+            step(); torch.cuda.synchronize()
+            if rank == 0:
                 eng.ctx.profile(True)
-                for _ in range(args.profile_steps):
-                    step()
+            for _ in range(args.profile_steps):
+                step()
+            if rank == 0:
                 store.update(eng.ctx.profile_collect())
                 eng.ctx.profile(False)
-            eng.ctx.set_overlap(not args.no_overlap)
+        eng.ctx.set_overlap(not args.no_overlap)
+        trainer.barrier()
+    out = None
+    if rank == 0:
         detect = detect_bench(eng, x)
         dom = prof.get(DOMINANT)
         roofline = None

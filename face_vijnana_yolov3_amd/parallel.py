@@ -68,7 +68,11 @@ class DataParallelTrainer(object):
             if not dist.is_initialized():
                 os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
                 os.environ.setdefault('MASTER_PORT', '29500')
-                dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=engine.dev)
+                backend = os.environ.get('FV_DIST_BACKEND', 'nccl')  # 'nccl' IS RCCL on ROCm; gloo only to rehearse on one GPU
+                if backend == 'nccl':
+                    dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=engine.dev)
+                else:
+                    dist.init_process_group(backend, rank=self.rank, world_size=self.world)
             # identical start on every rank
             dist.broadcast(engine.params, 0)
             dist.broadcast(engine.state, 0)
