@@ -84,6 +84,7 @@ def _declare(L):
         'fv_bn_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp, vp, vp, vp]),
         'fv_mse_loss_grad': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
         'fv_fd_loss_grad': (i32, [vp, vp, vp, i32, i32, vp, vp]),
+        'fv_letterbox': (i32, [vp, vp, i32, i32, i32, vp, ctypes.POINTER(ctypes.c_int32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -121,6 +121,19 @@ class TrainingSequence(object):
             images.append(img)
         return ({'input1': np.asarray(images)}, {'output': np.asarray(gts)})
 
+    def get_raw(self, index):
+        """Same batch, but images stay raw uint8 (decoded only): the letterbox then runs on the
+        device (fv_letterbox).  -> (list of HxWx3 uint8 arrays, (b,G,G,6) float32 GT tensors)."""
+        names = self.file_names[index * self.batch_size:(index + 1) * self.batch_size]
+        raws, gts = [], []
+        for name in names:
+            raw = self.loader(os.path.join(self.raw_data_path, name))
+            df = self.groups[name]
+            gts.append(encode_gt(df.iloc[:, 3:7].values, raw.shape[0], raw.shape[1], self.image_size, self.grid,
+                                 self.nn_arch['bb_info_c_size']))
+            raws.append(raw)
+        return raws, np.asarray(gts, np.float32)
+
 
 def _pil_loader(path):
     from PIL import Image

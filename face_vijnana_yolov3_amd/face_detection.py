@@ -22,7 +22,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import data
-from .postproc import BoundBox, decode_nms, to_boundboxes
+from .postproc import BoundBox, decode_nms, letterbox_device, to_boundboxes
 
 DEBUG = True
 
@@ -107,18 +107,21 @@ class FaceDetector(object):
             order = rng.permutation(steps)  # Keras fit_generator shuffles batch order (shuffle=True)
             if self.rank == 0:
                 print('Epoch %d/%d' % (epoch + 1, hp['epochs']))
-            nxt = pool.submit(seq.__getitem__, int(order[0]))
+            # loader threads only decode JPEGs + encode GT; the letterbox runs on the device
+            nxt = pool.submit(seq.get_raw, int(order[0]))
             for k in range(steps):
-                xb, yb = nxt.result()
+                raws, y = nxt.result()
                 if k + 1 < steps:
-                    nxt = pool.submit(seq.__getitem__, int(order[k + 1]))
-                x = xb['input1'].astype(np.float32); y = yb['output'].astype(np.float32)
+                    nxt = pool.submit(seq.get_raw, int(order[k + 1]))
                 if self.world > 1:  # contiguous tower slices, remainder to the last (multi_gpu_model)
-                    per = x.shape[0] // self.world
+                    per = len(raws) // self.world
                     lo = self.rank * per
-                    hi = x.shape[0] if self.rank == self.world - 1 else lo + per
-                    x, y = x[lo:hi], y[lo:hi]
-                loss = trainer.train_on_batch(torch.from_numpy(x), torch.from_numpy(y), hp['lr'], hp['beta_1'],
+                    hi = len(raws) if self.rank == self.world - 1 else lo + per
+                    raws, y = raws[lo:hi], y[lo:hi]
+                x = torch.empty((len(raws), self.image_size, self.image_size, 3), dtype=torch.float32, device=self.model.dev)
+                for b, raw in enumerate(raws):
+                    letterbox_device(self.model.ctx, raw, self.image_size, out=x[b])
+                loss = trainer.train_on_batch(x, torch.from_numpy(y), hp['lr'], hp['beta_1'],
                                               hp['beta_2'], hp.get('decay', 0.0))
                 if self.rank == 0:
                     print('%d/%d - loss: %.4f' % (k + 1, steps, float(loss.item())))
@@ -131,7 +134,9 @@ class FaceDetector(object):
     # ------------------------------------------------------------------ detect (fd.py:885-949)
     def detect(self, image):
         """image: (1,S,S,3) array in [0,1] -> list[BoundBox], ascending score, at most num_cands."""
-        y = self.model.predict_device(np.asarray(image, dtype=np.float32))
+        import torch
+        x = image if torch.is_tensor(image) else np.asarray(image, dtype=np.float32)
+        y = self.model.predict_device(x)
         res = decode_nms(self.model.ctx, y, self.image_size, self.hps['face_conf_th'], self.hps['nms_iou_th'],
                          self.hps['num_cands'])
         return to_boundboxes(res, 0)
@@ -172,8 +177,9 @@ class FaceDetector(object):
 
     def _run_file(self, file_name):
         raw = data._pil_loader(file_name)
-        img, geom = data.letterbox(raw, self.image_size)
-        boxes = self.detect(img[np.newaxis, :])
+        # letterbox on the device (fv_letterbox); data.letterbox is the CPU form of the same formula
+        img, geom = letterbox_device(self.model.ctx, raw, self.image_size)
+        boxes = self.detect(img[None])
         self._project_back(boxes, geom)
         return raw, boxes
 

@@ -66,3 +66,21 @@ def to_boundboxes(res, img=0):
     o = res['obj'][img, :c].cpu().numpy()
     s = res['score'][img, :c].cpu().numpy()
     return [BoundBox(b[k, 0], b[k, 1], b[k, 2], b[k, 3], objness=o[k], classes=[s[k]]) for k in range(c)]
+
+
+def letterbox_device(ctx, raw_u8, image_size, out=None):
+    """uint8 HxWx3 (numpy or CUDA tensor) -> (float32 CUDA tensor (S,S,3), geometry tuple
+    (h, w, pad_t, pad_b, pad_l, pad_r)) -- the device form of data.letterbox
+    (reference face_detection.py:112-147)."""
+    import ctypes
+    import torch
+    t = raw_u8 if torch.is_tensor(raw_u8) else torch.from_numpy(np.array(raw_u8, dtype=np.uint8, copy=True))
+    assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3
+    t = t.cuda().contiguous()
+    h, w = int(t.shape[0]), int(t.shape[1])
+    S = int(image_size)
+    if out is None:
+        out = torch.empty((S, S, 3), dtype=torch.float32, device=t.device)
+    geom = (ctypes.c_int32 * 6)()
+    ctx.check(lib().fv_letterbox(ctx.handle, ptr(t), h, w, S, ptr(out), geom), 'fv_letterbox')
+    return out, (h, w, geom[2], geom[3], geom[4], geom[5])

@@ -171,6 +171,12 @@ int fv_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale, c
  * dbias[C] = column sums of dy (may be NULL). */
 int fv_mse_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int c_pad,
                      float* loss, float* dy, float* dbias);
+/* Letterbox preprocessing (SURVEY 8f "next" row 1): replaces image/255 -> cv2.resize(INTER_CUBIC)
+ * -> cv2.copyMakeBorder(zeros) of fd.py:112-147 / 656-694 / 798-835.  src: uint8 [h][w][3] (device),
+ * dst: float32 [S][S][3]; geom (host, may be NULL) receives w_p, h_p, pad_t, pad_b, pad_l, pad_r.
+ * Geometry is exact; pixels follow OpenCV's bicubic (a=-0.75) in fp32 (parity unpinned vs cv2). */
+int fv_letterbox(fv_ctx* ctx, const uint8_t* src, int h, int w, int image_size, float* dst, int32_t* geom);
+
 /* fd_loss (fd.py:59-64) -- DEFINED BUT NEVER USED by the reference (every compile() passes
  * loss='mse', fd.py:335/366/370/381); provided as an operator only, not wired into fv_train_step.
  * yp, yt [cells][6]; per cell (BCE(y0,p0) + mean_{c=1..4} sqrt((y_c-p_c)^2) + BCE(y5,p5))/3 with

@@ -29,6 +29,42 @@ def letterbox_geometry(h, w, image_size):
     return w_p, h_p, pad_t, pad_b, pad_l, pad_r
 
 
+def letterbox_pixels(raw_u8, image_size):
+    """Plain-loop float64 restatement of image/255 -> bicubic resize (a=-0.75, half-pixel centres,
+    replicated border = OpenCV INTER_CUBIC's definition) -> zero pad (face_detection.py:112-147).
+    PARITY UNPINNED against cv2 (not installed): used to check the product's CPU and device
+    letterbox against one independent statement of the same formula."""
+    raw = np.asarray(raw_u8, np.float64) / 255
+    h, w = raw.shape[:2]
+    S = image_size
+    w_p, h_p, pt, pb, pl, pr = letterbox_geometry(h, w, S)
+
+    def wts(t):
+        a = -0.75
+        w0 = ((a * (t + 1) - 5 * a) * (t + 1) + 8 * a) * (t + 1) - 4 * a
+        w1 = ((a + 2) * t - (a + 3)) * t * t + 1
+        w2 = ((a + 2) * (1 - t) - (a + 3)) * (1 - t) * (1 - t) + 1
+        return [w0, w1, w2, 1 - w0 - w1 - w2]
+
+    out = np.zeros((S, S, 3), np.float64)
+    xs = []
+    for xi in range(w_p):
+        fx = (xi + 0.5) * (w / w_p) - 0.5
+        sx = math.floor(fx)
+        xs.append(([min(max(sx - 1 + i, 0), w - 1) for i in range(4)], wts(fx - sx)))
+    for yi in range(h_p):
+        fy = (yi + 0.5) * (h / h_p) - 0.5
+        sy = math.floor(fy)
+        wy = wts(fy - sy)
+        rows = [raw[min(max(sy - 1 + j, 0), h - 1)] for j in range(4)]
+        for xi, (ix, wx) in enumerate(xs):
+            acc = 0.0
+            for j in range(4):
+                acc = acc + wy[j] * sum(wx[i] * rows[j][ix[i]] for i in range(4))
+            out[pt + yi, pl + xi] = acc
+    return out
+
+
 # ----------------------------------------------------------------------------- GT encoder
 def gt_encode_image(rows, h, w, image_size=416, grid=13, channels=6):
     """face_detection.py:150-202 for one image.

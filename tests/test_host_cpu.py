@@ -91,3 +91,12 @@ def test_shard_files():
     parts = [shard_files(names, 4, r) for r in range(4)]
     assert sum(parts, []) == names and max(len(p) for p in parts) == 3
     assert shard_files(names[:2], 4, 3) == []
+
+
+def test_cpu_letterbox_matches_oracle_statement():
+    from oracle import host_oracle
+    rng = np.random.default_rng(5)
+    for (h, w) in [(37, 61), (80, 45), (64, 64), (20, 100)]:
+        raw = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got, _ = data.letterbox(raw, 64)
+        np.testing.assert_allclose(got, host_oracle.letterbox_pixels(raw, 64), rtol=0, atol=1e-12)

@@ -110,3 +110,20 @@ def test_invalid_arguments_report_errors(ctx):
         decode_nms(ctx, torch.zeros((1, 13, 13, 6), device='cuda'), 416, 0.5, 0.5, 0)
     r = decode_nms(ctx, torch.zeros((0, 13, 13, 6), device='cuda'), 416, 0.5, 0.5, 60)
     assert r['count'].numel() == 0
+
+
+@pytest.mark.parametrize('h,w,S', [(37, 61, 64), (80, 45, 64), (64, 64, 64), (480, 640, 416), (601, 333, 416), (1080, 1920, 416)])
+def test_device_letterbox(ctx, h, w, S):
+    """fv_letterbox: geometry exact; pixels within fp32 rounding of the float64 statement of the same
+    bicubic formula (cv2 itself is absent: parity unpinned)."""
+    from face_vijnana_yolov3_amd import data
+    from face_vijnana_yolov3_amd.postproc import letterbox_device
+    rng = np.random.default_rng(h * 1000 + w)
+    raw = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    out, geom = letterbox_device(ctx, raw, S)
+    want, wgeom = data.letterbox(raw, S)
+    assert tuple(geom) == tuple(wgeom)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=3e-6)
+    w_p, h_p, pt, pb, pl, pr = data.letterbox_geometry(h, w, S)
+    o = out.cpu().numpy()
+    assert o[:pt].sum() == 0 and o[S - pb:].sum() == 0 and o[:, :pl].sum() == 0 and o[:, S - pr:].sum() == 0
