@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libfv_hotpath.so')
+LIB_PATH = os.environ.get('FV_LIB_PATH') or os.path.join(_PKG, 'libfv_hotpath.so')  # FV_LIB_PATH: dev A/B of two builds
 _lib = None
 
 c_void_p, c_int, c_double, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_char_p

@@ -201,16 +201,19 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bsm[brow + j * 32 * LDT + kc * 8]);
         };
+        // k-major order: consecutive MFMAs rotate over all MB*NB accumulators, so an accumulator is
+        // re-used only every MB*NB-th instruction (dependent-accumulator latency never on the issue path)
         auto mfma_chunk = [&](const float4 (&af)[MB], const float4 (&bf)[NB]) {
 #pragma unroll
-            for (int i = 0; i < MB; ++i)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const float av = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
+                        const float bv = e == 0 ? bf[j].x : e == 1 ? bf[j].y : e == 2 ? bf[j].z : bf[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
         };
 
         if (s_begin < s_end) {
