@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=1)
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-overlap', action='store_true', help='serialise wgrad on the main stream (A/B aid)')
+    ap.add_argument('--no-detect', action='store_true', help='skip the detect-path measurement (PMC passes)')
     return ap.parse_args()
 
 
@@ -171,13 +172,24 @@ def main():
         trainer.barrier()
     out = None
     if rank == 0:
-        detect = detect_bench(eng, x)
+        detect = None if args.no_detect else detect_bench(eng, x)
         dom = prof.get(DOMINANT)
         roofline = None
+        traffic = None   # HBM-side bytes per launch from committed rocprofv3 PMC passes (cannot be read live)
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+            tk = tj.get('conv_kernel<128, 2, 2, false>')
+            if tk and B == PER_GPU_BATCH and S == IMAGE_SIZE:
+                traffic = dict(bytes_per_launch=round((tk['fetch_MB_per_launch'] + tk['write_MB_per_launch']) * 1e6),
+                               source='profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, '
+                                      'FETCH_SIZE x2 gfx950 correction; fabric-side requests, Infinity-Cache hits included)')
+        except (OSError, ValueError, KeyError):
+            pass
         if dom and dom['ms'] > 0:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
             roofline = dict(bound='mfma', achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                            frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None, kernel=DOMINANT,
+                            frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, kernel=DOMINANT,
+                            algorithmic_bytes_per_launch=round(dom['bytes'] / dom['launches']),
                             mode='exclusive: instrumented steps run with fv_set_overlap(0)',
                             launches_per_step=dom['launches'] // max(args.profile_steps, 1),
                             avg_launch_ms=round(dom['ms'] / dom['launches'], 4),
