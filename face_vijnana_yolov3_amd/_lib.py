@@ -85,6 +85,14 @@ def _declare(L):
         'fv_mse_loss_grad': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
         'fv_fd_loss_grad': (i32, [vp, vp, vp, i32, i32, vp, vp]),
         'fv_letterbox': (i32, [vp, vp, i32, i32, i32, vp, ctypes.POINTER(ctypes.c_int32)]),
+        'fv_yolov3_num_layers': (i32, []),
+        'fv_yolov3_layer': (i32, [i32, i32, ctypes.POINTER(LayerDesc)]),
+        'fv_yolov3_param_count': (i64, [i32]),
+        'fv_yolov3_state_count': (i64, [i32]),
+        'fv_yolov3_workspace_bytes': (sz, [i32, i32, i32]),
+        'fv_yolov3_forward': (i32, [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, vp, vp]),
+        'fv_yolo_decode_nms': (i32, [vp, vp, vp, vp, i32, i32, ctypes.POINTER(f32), f32, f64, i32, i32, i32, i32, i32,
+                                     vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -24,3 +24,4 @@ int fv_ew_bn_fold_all(fv_ctx* ctx, const float* params, const float* state, int 
                       const long long* beta_off, const long long* mean_off, const long long* var_off, float eps, int total,
                       float* scale, float* shift);
 int fv_ew_fd_loss(fv_ctx* ctx, const float* yp, const float* yt, int cells, int Cpad, float* loss, float* dy);
+int fv_ew_upsample_concat(fv_ctx* ctx, const float* src, const float* skip, float* out, int B, int Hs, int Ws, int C1, int C2);

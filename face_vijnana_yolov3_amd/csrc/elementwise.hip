@@ -453,3 +453,30 @@ int fv_ew_fd_loss(fv_ctx* ctx, const float* yp, const float* yt, int cells, int 
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }
+
+// UpSampling2D(2) (nearest) of src [B][Hs][Ws][C1] concatenated in front of skip [B][2Hs][2Ws][C2]
+// (reference yolov3_detect.py:282-283, 298-299) -> out [B][2Hs][2Ws][C1+C2]
+namespace {
+__global__ __launch_bounds__(256) void upsample_concat_kernel(const float4* __restrict__ src, const float4* __restrict__ skip,
+                                                              float4* __restrict__ out, int B, int Hs, int Ws, int C1, int C2) {
+    const int c4 = (C1 + C2) >> 2, c14 = C1 >> 2, c24 = C2 >> 2;
+    const long long n4 = (long long)B * (2 * Hs) * (2 * Ws) * c4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4);
+        const long long pix = i / c4;
+        const int w = (int)(pix % (2 * Ws)), h = (int)((pix / (2 * Ws)) % (2 * Hs)), b = (int)(pix / ((long long)4 * Hs * Ws));
+        out[i] = c < c14 ? src[(((long long)b * Hs + (h >> 1)) * Ws + (w >> 1)) * c14 + c] : skip[pix * c24 + (c - c14)];
+    }
+}
+}  // namespace
+
+int fv_ew_upsample_concat(fv_ctx* ctx, const float* src, const float* skip, float* out, int B, int Hs, int Ws, int C1, int C2) {
+    FV_REQUIRE(ctx, C1 % 4 == 0 && C2 % 4 == 0, "upsample_concat: channels must be multiples of 4");
+    const long long n4 = (long long)B * 4 * Hs * Ws * ((C1 + C2) / 4);
+    FvProfScope ps(ctx, "upsample_concat_kernel", 0.0, 4.0 * B * Hs * Ws * (C1 + 8.0 * (C1 + C2) / 2 + 4.0 * C2));
+    long long g = (n4 + 255) / 256;
+    hipLaunchKernelGGL(upsample_concat_kernel, dim3((unsigned)(g > 2048 ? 2048 : (g < 1 ? 1 : g))), dim3(256), 0, ctx->stream,
+                       (const float4*)src, (const float4*)skip, (float4*)out, B, Hs, Ws, C1, C2);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}

@@ -1,0 +1,93 @@
+"""Secondary path: the full three-scale YOLOv3 model of the reference (make_yolov3_model,
+yolov3_detect.py:217-311) and its decode / NMS chain (yolov3_detect.py:335-444, driver
+yolov3_detect.py:_main_ :545-610), on the device.  FaceDetector does not use this; it exists
+because SURVEY 8a-17/18 list it as part of the reference's hot-path files."""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import Context, LayerDesc, lib, ptr
+
+COCO_ANCHORS = [[116, 90, 156, 198, 373, 326], [30, 61, 62, 45, 59, 119], [10, 13, 16, 30, 33, 23]]  # yd.py:560
+
+
+def yolov3_layer_table(out_channels=255):
+    L = lib()
+    out = []
+    for i in range(L.fv_yolov3_num_layers()):
+        d = LayerDesc()
+        assert L.fv_yolov3_layer(i, out_channels, ctypes.byref(d)) == 0
+        out.append({f: getattr(d, f) for f, _ in LayerDesc._fields_})
+    return out
+
+
+class Yolov3(object):
+    def __init__(self, device=0, out_channels=255, ctx=None):
+        self.ctx = ctx or Context(device)
+        self.dev = torch.device('cuda', self.ctx.device)
+        self.out_channels = int(out_channels)
+        self.nclass = self.out_channels // 3 - 5
+        self.layers = yolov3_layer_table(self.out_channels)
+        self.n_params = int(lib().fv_yolov3_param_count(self.out_channels))
+        self.n_state = int(lib().fv_yolov3_state_count(self.out_channels))
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.dev)
+        self.state = torch.zeros(self.n_state, dtype=torch.float32, device=self.dev)
+        self._ws = {}
+
+    def set_params(self, params, state):
+        self.params.copy_(torch.as_tensor(params, dtype=torch.float32).reshape(-1))
+        self.state.copy_(torch.as_tensor(state, dtype=torch.float32).reshape(-1))
+
+    def load_darknet(self, path_or_bytes):
+        """Full Darknet yolov3.weights (conv index order 0..105; yd.py:90-121)."""
+        from .weights import header_len
+        buf = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, 'rb').read()
+        data = np.frombuffer(buf, dtype='<f4', offset=header_len(buf))
+        p = np.zeros(self.n_params, np.float32); s = np.zeros(self.n_state, np.float32)
+        off = 0
+        for d in sorted(self.layers, key=lambda d: d['darknet_index']):
+            k, cin, cout = d['ksize'], d['cin'], d['cout']
+            n = cout * cin * k * k
+            if d['has_bn']:
+                for dst, o in ((p, d['beta_off']), (p, d['gamma_off']), (s, d['mean_off']), (s, d['var_off'])):
+                    dst[o:o + cout] = data[off:off + cout]; off += cout
+            else:
+                p[d['beta_off']:d['beta_off'] + cout] = data[off:off + cout]; off += cout
+            p[d['w_off']:d['w_off'] + n] = data[off:off + n].reshape(cout, cin, k, k).transpose(0, 2, 3, 1).reshape(-1); off += n
+        self.set_params(p, s)
+        return off
+
+    def predict_device(self, x):
+        x = torch.as_tensor(x).to(device=self.dev, dtype=torch.float32).contiguous()
+        B, S = x.shape[0], x.shape[1]
+        key = (B, S)
+        if key not in self._ws:
+            n = int(lib().fv_yolov3_workspace_bytes(B, S, self.out_channels))
+            self._ws = {key: torch.empty(n, dtype=torch.uint8, device=self.dev)}
+        ws = self._ws[key]
+        ys = [torch.empty((B, S // d, S // d, self.out_channels), dtype=torch.float32, device=self.dev) for d in (32, 16, 8)]
+        rc = lib().fv_yolov3_forward(self.ctx.handle, ptr(self.params), ptr(self.state), ptr(x), B, S, self.out_channels, ptr(ws),
+                                     ws.numel(), ptr(ys[0]), ptr(ys[1]), ptr(ys[2]))
+        self.ctx.check(rc, 'fv_yolov3_forward')
+        return ys
+
+
+def decode_nms(ctx, y13, y26, y52, image_hw, net_hw=(416, 416), anchors=COCO_ANCHORS, obj_thresh=0.5, nms_thresh=0.45):
+    """One image: three (g,g,3*(5+nclass)) float32 CUDA tensors -> dict(boxes (n,4) int32 image
+    pixels, objness (n,), classes (n,nclass) with suppressed entries zeroed), reference list order."""
+    g = int(y13.shape[-3])
+    nclass = int(y13.shape[-1]) // 3 - 5
+    cap = g * g + 2 * (2 * g) * (2 * g) + (4 * g) * (4 * g)   # kept anchors: 1 @g, 2 @2g, 1 @4g (skip list)
+    dev = y13.device
+    boxes = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    obj = torch.empty((cap,), dtype=torch.float32, device=dev)
+    cls = torch.empty((cap, nclass), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+    anc = (ctypes.c_float * 18)(*[float(v) for row in anchors for v in row])
+    rc = lib().fv_yolo_decode_nms(ctx.handle, ptr(y13.contiguous()), ptr(y26.contiguous()), ptr(y52.contiguous()), g, nclass, anc,
+                                  float(obj_thresh), float(nms_thresh), int(net_hw[0]), int(net_hw[1]), int(image_hw[0]),
+                                  int(image_hw[1]), cap, ptr(boxes), ptr(obj), ptr(cls), ptr(cnt))
+    ctx.check(rc, 'fv_yolo_decode_nms')
+    n = int(cnt.item())
+    return dict(boxes=boxes[:n], objness=obj[:n], classes=cls[:n])

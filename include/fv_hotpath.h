@@ -177,6 +177,32 @@ int fv_mse_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int rows, in
  * Geometry is exact; pixels follow OpenCV's bicubic (a=-0.75) in fp32 (parity unpinned vs cv2). */
 int fv_letterbox(fv_ctx* ctx, const uint8_t* src, int h, int w, int image_size, float* dst, int32_t* geom);
 
+/* ------------------------------------------------------------------ secondary: three-scale YOLOv3
+ * (SURVEY 8a-17/18).  The reference builds this graph in make_yolov3_model (yd.py:217-311) and
+ * runs it only from yolov3_detect.py:_main_ (COCO demo: yd.py:596-598 decode, do_nms); FaceDetector
+ * discards it.  Inference only.  Flat layout: the 52 base layers exactly as fv_layer(0..51), then
+ * the 23 layers 75..105 (fv_yolov3_layer: role 4 = conv+BN+leaky, role 5 = detection conv with bias
+ * at beta_off, linear).  out_channels = 3*(5+classes) (255 for COCO). */
+int fv_yolov3_num_layers(void);                                   /* 75 */
+int fv_yolov3_layer(int i, int out_channels, fv_layer_desc* out);
+int64_t fv_yolov3_param_count(int out_channels);                  /* 61 949 149 at 255 */
+int64_t fv_yolov3_state_count(int out_channels);                  /* 52 608 */
+size_t fv_yolov3_workspace_bytes(int batch, int image_size, int out_channels);
+/* replaces yolov3.predict (yd.py:590): y13/y26/y52 = [batch][S/32|S/16|S/8]^2[out_channels] */
+int fv_yolov3_forward(fv_ctx* ctx, const float* params, const float* bn_state, const float* x, int batch,
+                      int image_size, int out_channels, void* workspace, size_t workspace_bytes,
+                      float* y13, float* y26, float* y52);
+/* replaces decode_netout x3 (yd.py:335-387, with its anchor skip list), correct_yolo_boxes
+ * (yd.py:389-404) and do_nms (yd.py:426-444) for ONE image: outputs in the reference's list order;
+ * boxes [capacity][4] int32 xmin,ymin,xmax,ymax in image pixels, objness [capacity],
+ * classes [capacity][nclass] (suppressed entries zeroed), count (device int).  anchors18: host
+ * floats, scale 0 first.  capacity <= 8192.  A zero-area pair (ZeroDivisionError in the reference)
+ * does not suppress. */
+int fv_yolo_decode_nms(fv_ctx* ctx, const float* y13, const float* y26, const float* y52, int grid0, int nclass,
+                       const float* anchors18, float obj_thresh, double nms_thresh, int net_h, int net_w,
+                       int image_h, int image_w, int capacity, int32_t* boxes, float* objness, float* classes,
+                       int32_t* count);
+
 /* fd_loss (fd.py:59-64) -- DEFINED BUT NEVER USED by the reference (every compile() passes
  * loss='mse', fd.py:335/366/370/381); provided as an operator only, not wired into fv_train_step.
  * yp, yt [cells][6]; per cell (BCE(y0,p0) + mean_{c=1..4} sqrt((y_c-p_c)^2) + BCE(y5,p5))/3 with

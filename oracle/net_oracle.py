@@ -192,3 +192,123 @@ def fwd_flops_per_image(image_size=416):
         hw = (image_size // div) ** 2
         total += 2 * hw * e['k'] ** 2 * e['cin'] * e['cout']
     return total
+
+
+# ----------------------------------------------------------------------------- full YOLOv3 (secondary)
+def yolov3_extra_table(nclass_ch=255):
+    """Layers 75..105 of make_yolov3_model (yolov3_detect.py:269-308), in execution order:
+    (darknet_idx, k, cin, cout, bn_leaky, src) where src names the input tensor:
+    'prev', 'base' (13x13x1024 base output), 'route79'/'route91' (branch inputs of the 1x1 before
+    UpSampling2D), 'cat61' (concat[upsampled, skip_61]) and 'cat36'."""
+    t = []
+    c = 1024
+    for i, (idx, k, co) in enumerate([(75, 1, 512), (76, 3, 1024), (77, 1, 512), (78, 3, 1024), (79, 1, 512)]):
+        t.append((idx, k, c, co, True, 'base' if i == 0 else 'prev')); c = co
+    t.append((80, 3, 512, 1024, True, 'prev'))
+    t.append((81, 1, 1024, nclass_ch, False, 'prev'))        # yolo_82
+    t.append((84, 1, 512, 256, True, 'route79'))
+    c = 768
+    for i, (idx, k, co) in enumerate([(87, 1, 256), (88, 3, 512), (89, 1, 256), (90, 3, 512), (91, 1, 256)]):
+        t.append((idx, k, c, co, True, 'cat61' if i == 0 else 'prev')); c = co
+    t.append((92, 3, 256, 512, True, 'prev'))
+    t.append((93, 1, 512, nclass_ch, False, 'prev'))         # yolo_94
+    t.append((96, 1, 256, 128, True, 'route91'))
+    c = 384
+    for i, (idx, k, co) in enumerate([(99, 1, 128), (100, 3, 256), (101, 1, 128), (102, 3, 256), (103, 1, 128), (104, 3, 256)]):
+        t.append((idx, k, c, co, True, 'cat36' if i == 0 else 'prev')); c = co
+    t.append((105, 1, 256, nclass_ch, False, 'prev'))        # yolo_106
+    return t
+
+
+def yolov3_layout(nclass_ch=255):
+    """Flat layout of the full model: the 52 base layers exactly as in param_layout() (without the
+    FaceDetector head), then the extra layers: kernel OHWI, then gamma/beta (BN layers) or bias."""
+    ents, _, _ = param_layout()
+    ents = [dict(e) for e in ents[:-1]]
+    off = ents[-1]['beta_off'] + ents[-1]['cout']
+    soff = ents[-1]['var_off'] + ents[-1]['cout']
+    for (idx, k, cin, cout, bn, src) in yolov3_extra_table(nclass_ch):
+        e = dict(name='conv_%d' % idx, idx=idx, k=k, s=1, cin=cin, cout=cout, role='extra', has_bn=bn, src=src)
+        e['w_off'] = off; off += cout * k * k * cin
+        if bn:
+            e['gamma_off'] = off; off += cout
+            e['beta_off'] = off; off += cout
+            e['mean_off'] = soff; soff += cout
+            e['var_off'] = soff; soff += cout
+        else:
+            e['bias_off'] = off; off += cout
+        ents.append(e)
+    return ents, off, soff
+
+
+def yolov3_init(seed=11, nclass_ch=255, dtype=torch.float32):
+    ents, n, ns = yolov3_layout(nclass_ch)
+    g = torch.Generator().manual_seed(seed)
+    p = torch.zeros(n, dtype=torch.float64); st = torch.zeros(ns, dtype=torch.float64)
+    for e in ents:
+        k, cin, cout = e['k'], e['cin'], e['cout']
+        cnt = cout * k * k * cin
+        p[e['w_off']:e['w_off'] + cnt] = torch.randn(cnt, generator=g, dtype=torch.float64) * math.sqrt(1.0 / (k * k * cin))
+        if e['has_bn']:
+            p[e['gamma_off']:e['gamma_off'] + cout] = 0.8 + 0.4 * torch.rand(cout, generator=g, dtype=torch.float64)
+            p[e['beta_off']:e['beta_off'] + cout] = 0.1 * torch.randn(cout, generator=g, dtype=torch.float64)
+            st[e['mean_off']:e['mean_off'] + cout] = 0.1 * torch.randn(cout, generator=g, dtype=torch.float64)
+            st[e['var_off']:e['var_off'] + cout] = 0.5 + torch.rand(cout, generator=g, dtype=torch.float64)
+        else:
+            p[e['bias_off']:e['bias_off'] + cout] = 0.1 * torch.randn(cout, generator=g, dtype=torch.float64)
+    return p.to(dtype), st.to(dtype)
+
+
+def yolov3_forward(params, state, x_nhwc, nclass_ch=255):
+    """Inference forward of make_yolov3_model (yolov3_detect.py:217-311): -> [yolo_82, yolo_94,
+    yolo_106] as NHWC tensors (B,S/32,S/32,C), (B,S/16,..), (B,S/8,..)."""
+    ents, _, _ = yolov3_layout(nclass_ch)
+    x = x_nhwc.permute(0, 3, 1, 2)
+    skip = None
+    t = {}
+    outs = []
+    nbase = 52
+
+    def block(e, x):
+        k, cin, cout = e['k'], e['cin'], e['cout']
+        w = params[e['w_off']:e['w_off'] + cout * k * k * cin].view(cout, k, k, cin)
+        z = _conv(x, w, k, e['s'])
+        if not e['has_bn']:
+            return z + params[e['bias_off']:e['bias_off'] + cout].view(1, -1, 1, 1)
+        mean = state[e['mean_off']:e['mean_off'] + cout]; var = state[e['var_off']:e['var_off'] + cout]
+        y = (z - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + BN_EPS) * params[e['gamma_off']:e['gamma_off'] + cout].view(1, -1, 1, 1) \
+            + params[e['beta_off']:e['beta_off'] + cout].view(1, -1, 1, 1)
+        return F.leaky_relu(y, LEAKY)
+
+    for li, e in enumerate(ents[:nbase]):
+        if e['role'] == 'res_a':
+            skip = x
+        x = block(e, x)
+        if e['role'] == 'res_b':
+            x = skip + x
+        if e['idx'] == 35:
+            t['skip36'] = x      # output of the add after conv_35 (Darknet layer 36)
+        if e['idx'] == 60:
+            t['skip61'] = x
+    t['base'] = x
+    prev = x
+    for e in ents[nbase:]:
+        src = e['src']
+        if src == 'prev':
+            inp = prev
+        elif src == 'base':
+            inp = t['base']
+        elif src == 'route79':
+            inp = t['out79']
+        elif src == 'route91':
+            inp = t['out91']
+        elif src == 'cat61':
+            inp = torch.cat([F.interpolate(prev, scale_factor=2, mode='nearest'), t['skip61']], dim=1)
+        else:
+            inp = torch.cat([F.interpolate(prev, scale_factor=2, mode='nearest'), t['skip36']], dim=1)
+        prev = block(e, inp)
+        if e['idx'] in (79, 91):
+            t['out%d' % e['idx']] = prev
+        if not e['has_bn']:
+            outs.append(prev.permute(0, 2, 3, 1).contiguous())
+    return outs
