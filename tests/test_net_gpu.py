@@ -171,3 +171,33 @@ def test_side_stream_overlap_equals_serial(eng):
     assert res[0][2] == res[1][2]
     d = (res[0][1] - res[1][1]).abs().max().item()
     assert d <= 1e-5 * res[1][1].abs().max().item() + 1e-9, d
+
+
+def test_config5_608_grid19(eng):
+    """BASELINE config 5: image_size 608 (grid 19 = the build's generalisation of the reference's
+    hard-coded CELL_SIZE=13).  One image: inference forward and a train step against the
+    oracle, plus detect post-processing on the 19x19 head."""
+    from face_vijnana_yolov3_amd.postproc import decode_nms
+    from oracle import net_oracle as no
+    from oracle import postproc as opp
+    p64, s64, x, yt = _setup(21, 1, 608)
+    y64, _ = no.forward(p64, s64, x, training=False)
+    y32, _ = no.forward(p64.float(), s64.float(), x.float(), training=False)
+    eng.set_params(p64.float(), s64.float())
+    y = eng.predict_device(x.float())
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (1, 19, 19, 6)
+    _within(y.cpu(), y64, y32, 'forward_infer 608')
+    got = decode_nms(eng.ctx, y, 608, 0.5, 0.5, 60)
+    want = opp.detect_postproc(y.cpu().numpy(), 608, 0.5, 0.5, 60)
+    for k in ('count', 'boxes', 'cell', 'score'):
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+    l64, g64, _ = no.train_step_grads(p64, s64, x, yt)
+    l32, g32, _ = no.train_step_grads(p64.float(), s64.float(), x.float(), yt.float())
+    eng.m = eng.v = eng.grads = None
+    loss = eng.forward_backward(x.float(), yt.float())
+    torch.cuda.synchronize()
+    assert abs(loss.item() - l64.item()) <= 4 * abs(l32.item() - l64.item()) + 1e-6 * abs(l64.item())
+    gn = (eng.grads.cpu().double() - g64).norm().item() / g64.norm().item()
+    gn32 = (g32.double() - g64).norm().item() / g64.norm().item()
+    assert gn <= 6 * gn32 + 1e-5, (gn, gn32)
