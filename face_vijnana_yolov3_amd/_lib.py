@@ -62,6 +62,7 @@ def _declare(L):
     i32, i64, f32, f64, vp, sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, c_void_p, ctypes.c_size_t
     sig = {
         'fv_set_overlap': (i32, [vp, i32]),
+        'fv_set_conv_dma': (i32, [vp, i32]),
         'fv_profile_enable': (i32, [vp, i32]),
         'fv_profile_collect': (i32, [vp, ctypes.POINTER(ProfileRec), i32, ctypes.POINTER(i32)]),
         'fv_num_layers': (i32, []),
@@ -129,6 +130,9 @@ class Context:
 
     def set_overlap(self, on):
         self.check(lib().fv_set_overlap(self._h, 1 if on else 0), 'fv_set_overlap')
+
+    def set_conv_dma(self, on):
+        self.check(lib().fv_set_conv_dma(self._h, 1 if on else 0), 'fv_set_conv_dma')
 
     def profile(self, on):
         self.check(lib().fv_profile_enable(self._h, 1 if on else 0), 'fv_profile_enable')

@@ -23,6 +23,7 @@ struct fv_ctx {
     // backward-pass overlap: weight-gradient kernels run on a side stream next to the
     // data-gradient / BN-backward chain (fv_set_overlap)
     bool overlap = true;
+    bool conv_dma = false;   // fv_set_conv_dma: LDS-DMA operand staging variant of the conv kernel
     hipStream_t side = nullptr;
     hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr};
     ~fv_ctx();

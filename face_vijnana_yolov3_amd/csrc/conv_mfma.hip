@@ -290,6 +290,205 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
     }
 }
 
+// one wave instruction: 64 lanes x 16 B from per-lane buffer offsets to LDS at lds_base + lane*16
+// (the address-space cast only exists in the device pass)
+__device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t& rsrc, float* lds_base, unsigned voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, soffset, 0, 0);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant (buffer_load_dwordx4 ... lds): operand tiles go HBM/L2 -> LDS without passing
+// through VGPRs.  One wave instruction writes 64 lanes x 16 B = 8 rows x 128 B contiguously, so the
+// LDS image is unpadded [row][32 floats]; bank conflicts of the ds_read_b128 fragment reads are
+// removed by an XOR swizzle of the 16-byte chunk position with ((row >> 1) & 7), applied on the
+// per-lane SOURCE address of the DMA and on the read address (CDNA4 guide rule 21).  Out-of-range
+// source offsets (padding taps, tail rows) deliver zeros.  Same tiling, K order and epilogue as
+// conv_kernel, so results are bit-identical.
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void conv_kernel_dma(const FvConvArgs a) {
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int MB = WTM / 32, NB = WTN / 32;
+    constexpr int BL = BN / 32;
+    constexpr int LD = BK;  // unpadded rows
+
+    __shared__ __attribute__((aligned(1024))) float As[2][BM * LD];
+    __shared__ __attribute__((aligned(1024))) float Bs[2][BN * LD];
+    __shared__ int rowoff[BM];
+    __shared__ float red[2][WAVES_M][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int cls = blockIdx.z;
+    const FvTaps& taps = a.taps[cls];
+    const int NT = (a.Nout + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = tile / NT, nt = tile - mt * NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int HWl = a.Hl * a.Wl;
+
+    if (tid < BM) {
+        int m = m0 + tid, off = -1;
+        if (m < a.M) {
+            int b = m / HWl, rem = m - b * HWl, oh = rem / a.Wl, ow = rem - oh * a.Wl;
+            off = ((b * a.Hout + oh * a.os + a.oph[cls]) * a.Wout + ow * a.os + a.opw[cls]) * a.Nout;
+        }
+        rowoff[tid] = off;
+    }
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((unsigned)a.B * a.Hin * a.Win * a.Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.w, 0, (int)((unsigned)a.Nout * a.Tw * a.Cin * 4u), 0x00020000);
+    // lane -> (row within the 8-row DMA group, chunk position); source chunk = position ^ swizzle(row)
+    const int csw = ((lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7)) * 4;   // floats
+    int a_pix[4], a_oh[4], a_ow[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int m = m0 + (tid >> 3) + 32 * p;
+        if (m < a.M) {
+            int b = m / HWl, rem = m - b * HWl, oh = rem / a.Wl, ow = rem - oh * a.Wl;
+            a_pix[p] = b * a.Hin; a_oh[p] = oh * a.is; a_ow[p] = ow * a.is;
+        } else {
+            a_pix[p] = 0; a_oh[p] = -(1 << 28); a_ow[p] = 0;
+        }
+    }
+    unsigned b_row[BL];
+#pragma unroll
+    for (int p = 0; p < BL; ++p) {
+        int n = n0 + (tid >> 3) + 32 * p;
+        b_row[p] = n < a.Nout ? (unsigned)(n * a.Tw * a.Cin + csw) * 4u : OOB;
+    }
+    const int cpk = a.Cin / BK;
+    const int nk = taps.n * cpk;
+    const int per = (nk + a.ksplit - 1) / a.ksplit;
+    const int s_begin = blockIdx.y * per;
+    const int s_end = min(nk, s_begin + per);
+    unsigned a_off[4];
+    int t = s_begin / cpk, ci = s_begin - t * cpk;
+    auto set_tap = [&](int tp) {
+        const int dh = taps.dh[tp], dw = taps.dw[tp];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int ih = a_oh[p] + dh, iw = a_ow[p] + dw;
+            bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+            a_off[p] = ok ? (unsigned)(((a_pix[p] + ih) * a.Win + iw) * a.Cin + csw) * 4u : OOB;
+        }
+    };
+    // wave w, instruction p covers rows [32p + 8w, 32p + 8w + 8): 1 KiB contiguous in the unpadded image
+    auto dma = [&](int buf) {
+        const int c0b = ci * BK * 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            lds_dma16(xr, &As[buf][(32 * p + 8 * wave) * LD], a_off[p], c0b);
+        const int wofs = (taps.wslot[t] * a.Cin) * 4 + c0b;
+#pragma unroll
+        for (int p = 0; p < BL; ++p)
+            lds_dma16(wr, &Bs[buf][(32 * p + 8 * wave) * LD], b_row[p], wofs);
+    };
+    auto advance = [&]() {
+        if (++ci == cpk) { ci = 0; ++t; if (t < taps.n) set_tap(t); }
+    };
+    const int sw = ((lane & 31) >> 1) & 7;   // read-side swizzle of this lane's rows
+    const int arow = (wm * WTM + (lane & 31)) * LD, brow = (wn * WTN + (lane & 31)) * LD;
+    auto readfrag = [&](const float* __restrict__ Asm, const float* __restrict__ Bsm, int kc, float4 (&af)[MB], float4 (&bf)[NB]) {
+        const int pos = ((kc * 2 + (lane >> 5)) ^ sw) * 4;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) af[i] = *reinterpret_cast<const float4*>(&Asm[arow + i * 32 * LD + pos]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bsm[brow + j * 32 * LD + pos]);
+    };
+    auto mfma_chunk = [&](const float4 (&af)[MB], const float4 (&bf)[NB]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const float av = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
+                    const float bv = e == 0 ? bf[j].x : e == 1 ? bf[j].y : e == 2 ? bf[j].z : bf[j].w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                }
+    };
+
+    if (s_begin < s_end) {
+        set_tap(t);
+        dma(0);
+        advance();
+    }
+    __syncthreads();   // drains the DMA (vmcnt) and orders it before the first fragment reads
+    for (int s = s_begin; s < s_end; ++s) {
+        const int cur = (s - s_begin) & 1;
+        if (s + 1 < s_end) { dma(cur ^ 1); advance(); }   // lands in the other buffer while this tile computes
+        float4 af0[MB], bf0[NB], af1[MB], bf1[NB];
+        readfrag(As[cur], Bs[cur], 0, af0, bf0);
+        readfrag(As[cur], Bs[cur], 1, af1, bf1);
+        mfma_chunk(af0, bf0);
+        readfrag(As[cur], Bs[cur], 2, af0, bf0);
+        mfma_chunk(af1, bf1);
+        readfrag(As[cur], Bs[cur], 3, af1, bf1);
+        mfma_chunk(af0, bf0);
+        mfma_chunk(af1, bf1);
+        __syncthreads();
+    }
+
+    const int half = lane >> 5, lc = lane & 31;
+    if (a.epi & FV_EPI_STATS) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { float v = acc[i][j][r]; s += v; q += v * v; }
+            s += __shfl_xor(s, 32);
+            q += __shfl_xor(q, 32);
+            if (half == 0) { red[0][wm][wn * WTN + j * 32 + lc] = s; red[1][wm][wn * WTN + j * 32 + lc] = q; }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Nout) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) { s += red[0][w][tid]; q += red[1][w][tid]; }
+            a.psum[(size_t)mt * a.Nout + n0 + tid] = s;
+            a.psq[(size_t)mt * a.Nout + n0 + tid] = q;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + lc;
+        const bool nv = n < a.Nout;
+        float sc = 1.0f, sh = 0.0f;
+        if ((a.epi & FV_EPI_AFFINE) && nv) {
+            if (a.scale) sc = a.scale[n];
+            if (a.shift) sh = a.shift[n];
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int off = rowoff[row];
+                if (off >= 0 && nv) {
+                    float v = acc[i][j][r];
+                    if (a.epi & FV_EPI_AFFINE) v = v * sc + sh;
+                    if (a.epi & FV_EPI_LEAKY) v = v > 0.0f ? v : v * a.leaky;
+                    if (a.epi & FV_EPI_ADD) v += a.addend[off + n];
+                    a.out[(size_t)blockIdx.y * a.split_stride + off + n] = v;
+                }
+            }
+    }
+}
+
 template <int BN, int WM_, int WN_, bool G>
 int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
     const int MT = (a.M + BM - 1) / BM, NT = (a.Nout + BN - 1) / BN;
@@ -302,6 +501,13 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
                           (double)a.M * a.nclass * a.Nout * ((a.epi & FV_EPI_ADD) ? 2 : 1)));
     FvConvArgs b = a;
     if (b.ksplit < 1) b.ksplit = 1;
+    if constexpr (!G) {
+        if (ctx->conv_dma) {   // measured neutral against the register-staged kernel; opt-in
+            hipLaunchKernelGGL((conv_kernel_dma<BN, WM_, WN_>), grid, dim3(256), 0, ctx->stream, b);
+            FV_LAUNCH_CHECK(ctx);
+            return FV_OK;
+        }
+    }
     hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G>), grid, dim3(256), 0, ctx->stream, b);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;

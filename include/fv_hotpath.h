@@ -48,6 +48,9 @@ int fv_set_stream(fv_ctx* ctx, void* stream);
  * of a gradient range (fv_bucket_fn) and before it returns.  on = 0 serialises everything on the
  * context's stream (default: on). */
 int fv_set_overlap(fv_ctx* ctx, int on);
+/* Conv operand staging through LDS-DMA (buffer_load ... lds, XOR-swizzled unpadded LDS image)
+ * instead of VGPR staging.  Bit-identical results; measured neutral on MI355X (default: off). */
+int fv_set_conv_dma(fv_ctx* ctx, int on);
 
 /* ------------------------------------------------------------------ per-kernel timing
  * Measurement aid with no counterpart in the reference (it has no profiler hooks):

@@ -218,3 +218,24 @@ def test_fd_loss_and_grad(ctx):
     assert abs(loss.item() - ref.item()) <= 2e-6 * abs(ref.item())
     torch.testing.assert_close(dy.cpu()[:, :6].double(), rg, rtol=2e-6, atol=1e-9)
     assert torch.count_nonzero(dy[:, 6:]) == 0
+
+
+@pytest.mark.parametrize('B,H,cin,cout,k,s', [(2, 13, 128, 256, 3, 1), (2, 16, 32, 64, 3, 2), (3, 13, 64, 32, 1, 1), (2, 13, 1024, 6, 3, 1)])
+def test_lds_dma_variant_is_bit_identical(ctx, B, H, cin, cout, k, s):
+    """fv_set_conv_dma: operands staged by buffer_load...lds into a swizzled LDS image; same K order,
+    so the result (incl. zero padding at the borders and the BN partials) is bit-identical."""
+    from face_vijnana_yolov3_amd import ops
+    x = _rand((B, H, H, cin), 71).cuda(); w = _rand((cout, k, k, cin), 72).cuda()
+    ref = ops.conv2d_forward(ctx, x, w, stride=s, stats=True)
+    ctx.set_conv_dma(True)
+    try:
+        got = ops.conv2d_forward(ctx, x, w, stride=s, stats=True)
+        dy = _rand((B, H // s, H // s, max(32, cout)), 73).cuda()
+        if cout < 32:
+            dy[..., cout:] = 0
+        dg = ops.conv2d_dgrad(ctx, dy, w, (H, H), s)
+    finally:
+        ctx.set_conv_dma(False)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    assert torch.equal(dg, ops.conv2d_dgrad(ctx, dy, w, (H, H), s))
