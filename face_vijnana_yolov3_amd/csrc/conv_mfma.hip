@@ -32,6 +32,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + pos;
 }
 
+// Phase stagger (speed only, never correctness).  The two workgroups that share a CU are dispatched
+// together, run tiles of equal length and therefore reach their epilogue / exit / next prologue at
+// the same moment: the matrix pipe idles there, and tile rounds quantise to multiples of 2 x 256.
+// One workgroup alone already saturates the pipe (tools/mfma_peak: 154 TF at 1 workgroup per CU), so
+// letting the second dispatch wave (linear ids 256..511) sleep for a quarter of a shared tile time
+// costs nothing and leaves every pair half a tile out of phase for the rest of the launch.
+__device__ __forceinline__ void phase_stagger(int enabled, int ksteps, int mfma_per_step) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (!enabled || lin < 256u || lin >= 512u) return;
+    // shared tile time T = 2 * ksteps * mfma_per_step * 64 cycles; wait T/4
+    const unsigned long long wait = (unsigned long long)ksteps * mfma_per_step * 32ull;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(64);
+}
+
 template <int BN, int WAVES_M, int WAVES_N, bool GATHER>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -39,8 +54,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
     constexpr int BL = BN / 32;  // B-tile float4 loads per thread
     static_assert(WAVES_M * WAVES_N == 4 && MB >= 1 && NB >= 1, "bad tiling");
 
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDT];
+    // one block: A double buffer, B double buffer; reused as the BM x BN output tile by the epilogue
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDT];
+    static_assert(2 * (BM + BN) * LDT >= BM * BN, "operand LDS must hold the output tile");
+    float (*As)[BM * LDT] = reinterpret_cast<float (*)[BM * LDT]>(smem);
+    float (*Bs)[BN * LDT] = reinterpret_cast<float (*)[BN * LDT]>(smem + 2 * BM * LDT);
     __shared__ int rowoff[BM];
     __shared__ float red[2][WAVES_M][BN];
 
@@ -216,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
                     }
         };
 
+        phase_stagger(a.stagger, s_end - s_begin, MB * NB * 16);
         if (s_begin < s_end) {
             set_tap(t);
             load();
@@ -264,6 +283,47 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
             a.psq[(size_t)mt * a.Nout + n0 + tid] = q;
         }
     }
+    if ((a.Nout & 3) == 0) {
+        // Wide store path.  In the accumulator layout a lane owns one output column and 16 scattered
+        // rows, i.e. 64 four-byte stores per lane and tile -- a store-issue-bound tail of ~10 us per
+        // tile.  Transpose the tile through the (now free) operand LDS and write whole 16-byte pieces:
+        // 4x fewer store instructions, every wave instruction covers two full 512-byte rows.
+        float* Cs = smem;
+        __syncthreads();         // every wave is done reading the operand tiles
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Cs[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BN + wn * WTN + j * 32 + lc] = acc[i][j][r];
+        __syncthreads();
+        constexpr int C4 = BN / 4;                   // float4 pieces per tile row
+        float* outp = a.out + (size_t)blockIdx.y * a.split_stride;
+#pragma unroll
+        for (int p = 0; p < BM * C4 / 256; ++p) {
+            const int f = tid + 256 * p, row = f / C4, c4 = (f % C4) * 4;
+            const int off = rowoff[row], n = n0 + c4;
+            if (off >= 0 && n < a.Nout) {
+                float4 v = *reinterpret_cast<const float4*>(&Cs[row * BN + c4]);
+                if (a.epi & FV_EPI_AFFINE) {
+                    if (a.scale) { const float4 s = *reinterpret_cast<const float4*>(a.scale + n); v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w; }
+                    if (a.shift) { const float4 s = *reinterpret_cast<const float4*>(a.shift + n); v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+                }
+                if (a.epi & FV_EPI_LEAKY) {
+                    v.x = v.x > 0.f ? v.x : v.x * a.leaky; v.y = v.y > 0.f ? v.y : v.y * a.leaky;
+                    v.z = v.z > 0.f ? v.z : v.z * a.leaky; v.w = v.w > 0.f ? v.w : v.w * a.leaky;
+                }
+                if (a.epi & FV_EPI_ADD) {
+                    const float4 s = *reinterpret_cast<const float4*>(a.addend + off + n);
+                    v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+                }
+                *reinterpret_cast<float4*>(outp + off + n) = v;
+            }
+        }
+        return;
+    }
+    // scalar path: output rows that are not 16-byte aligned (head: 6 channels; 255-channel detection convs)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int n = n0 + wn * WTN + j * 32 + lc;
@@ -501,6 +561,7 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
                           (double)a.M * a.nclass * a.Nout * ((a.epi & FV_EPI_ADD) ? 2 : 1)));
     FvConvArgs b = a;
     if (b.ksplit < 1) b.ksplit = 1;
+    b.stagger = ctx->stagger ? 1 : 0;
     if constexpr (!G) {
         if (ctx->conv_dma) {   // measured neutral against the register-staged kernel; opt-in
             hipLaunchKernelGGL((conv_kernel_dma<BN, WM_, WN_>), grid, dim3(256), 0, ctx->stream, b);
