@@ -63,7 +63,6 @@ def _declare(L):
     sig = {
         'fv_set_overlap': (i32, [vp, i32]),
         'fv_set_conv_dma': (i32, [vp, i32]),
-        'fv_set_stagger': (i32, [vp, i32]),
         'fv_profile_enable': (i32, [vp, i32]),
         'fv_profile_collect': (i32, [vp, ctypes.POINTER(ProfileRec), i32, ctypes.POINTER(i32)]),
         'fv_num_layers': (i32, []),
@@ -131,9 +130,6 @@ class Context:
 
     def set_overlap(self, on):
         self.check(lib().fv_set_overlap(self._h, 1 if on else 0), 'fv_set_overlap')
-
-    def set_stagger(self, on):
-        self.check(lib().fv_set_stagger(self._h, 1 if on else 0), 'fv_set_stagger')
 
     def set_conv_dma(self, on):
         self.check(lib().fv_set_conv_dma(self._h, 1 if on else 0), 'fv_set_conv_dma')

@@ -53,12 +53,6 @@ int fv_set_overlap(fv_ctx* ctx, int on) {
     return FV_OK;
 }
 
-int fv_set_stagger(fv_ctx* ctx, int on) {
-    if (!ctx) return FV_ERR_INVALID;
-    ctx->stagger = on != 0;
-    return FV_OK;
-}
-
 int fv_set_conv_dma(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;
     ctx->conv_dma = on != 0;

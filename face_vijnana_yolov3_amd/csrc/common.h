@@ -24,7 +24,6 @@ struct fv_ctx {
     // data-gradient / BN-backward chain (fv_set_overlap)
     bool overlap = true;
     bool conv_dma = false;   // fv_set_conv_dma: LDS-DMA operand staging variant of the conv kernel
-    bool stagger = true;     // fv_set_stagger: phase-stagger co-resident workgroups of the MFMA kernels
     hipStream_t side = nullptr;
     hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr};
     ~fv_ctx();

@@ -36,7 +36,6 @@ struct FvConvArgs {
     float leaky;
     int nclass;   // 1, or 4 for stride-2 data-gradient
     double alg_flops;  // algorithmic 2*MAC of this launch (profiling only)
-    int stagger;       // phase-stagger the second dispatch wave (set by the launcher from the context)
     int ksplit;        // >1: blockIdx.y owns a slice of the K steps and stores its raw partial to out + y*split_stride
     long long split_stride;
     int oph[4], opw[4];

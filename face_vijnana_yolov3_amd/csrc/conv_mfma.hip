@@ -32,21 +32,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + pos;
 }
 
-// Phase stagger (speed only, never correctness).  The two workgroups that share a CU are dispatched
-// together, run tiles of equal length and therefore reach their epilogue / exit / next prologue at
-// the same moment: the matrix pipe idles there, and tile rounds quantise to multiples of 2 x 256.
-// One workgroup alone already saturates the pipe (tools/mfma_peak: 154 TF at 1 workgroup per CU), so
-// letting the second dispatch wave (linear ids 256..511) sleep for a quarter of a shared tile time
-// costs nothing and leaves every pair half a tile out of phase for the rest of the launch.
-__device__ __forceinline__ void phase_stagger(int enabled, int ksteps, int mfma_per_step) {
-    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (!enabled || lin < 256u || lin >= 512u) return;
-    // shared tile time T = 2 * ksteps * mfma_per_step * 64 cycles; wait T/4
-    const unsigned long long wait = (unsigned long long)ksteps * mfma_per_step * 32ull;
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(64);
-}
-
 template <int BN, int WAVES_M, int WAVES_N, bool GATHER>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -234,7 +219,6 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
                     }
         };
 
-        phase_stagger(a.stagger, s_end - s_begin, MB * NB * 16);
         if (s_begin < s_end) {
             set_tap(t);
             load();
@@ -561,7 +545,6 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
                           (double)a.M * a.nclass * a.Nout * ((a.epi & FV_EPI_ADD) ? 2 : 1)));
     FvConvArgs b = a;
     if (b.ksplit < 1) b.ksplit = 1;
-    b.stagger = ctx->stagger ? 1 : 0;
     if constexpr (!G) {
         if (ctx->conv_dma) {   // measured neutral against the register-staged kernel; opt-in
             hipLaunchKernelGGL((conv_kernel_dma<BN, WM_, WN_>), grid, dim3(256), 0, ctx->stream, b);

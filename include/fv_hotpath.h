@@ -51,10 +51,6 @@ int fv_set_overlap(fv_ctx* ctx, int on);
 /* Conv operand staging through LDS-DMA (buffer_load ... lds, XOR-swizzled unpadded LDS image)
  * instead of VGPR staging.  Bit-identical results; measured neutral on MI355X (default: off). */
 int fv_set_conv_dma(fv_ctx* ctx, int on);
-/* Phase stagger of the MFMA kernels: workgroups of the second dispatch wave start a quarter tile
- * late so the two workgroups sharing a CU never reach their epilogues together (speed only;
- * default: on). */
-int fv_set_stagger(fv_ctx* ctx, int on);
 
 /* ------------------------------------------------------------------ per-kernel timing
  * Measurement aid with no counterpart in the reference (it has no profiler hooks):

@@ -34,8 +34,6 @@ def main():
     ap.add_argument('--only', default='')
     a = ap.parse_args()
     ctx = Context(0)
-    if os.environ.get('FV_STAGGER') == '0':
-        ctx.set_stagger(False)
     seen = {}
     for d in layer_table():
         key = (d['ksize'], d['stride'], d['cin'], d['cout'], a.size // d['in_div'])
