@@ -199,7 +199,10 @@ int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
     const int total_chunks = (a.M + KP - 1) / KP;
     // enough K-splits to fill the chip ~4 blocks deep, but at least 8 chunks of work per block
     int want = (256 * 8 + tiles - 1) / tiles;
-    int max_split = (total_chunks + 7) / 8;
+    // every block pays a fixed epilogue (64 atomics per lane): at least 8 chunks of work per block,
+    // 16 for 1x1 kernels (few tiles, so all parallelism comes from the split; measured +12 %)
+    const int min_chunks = ntap == 1 ? 16 : 8;
+    int max_split = (total_chunks + min_chunks - 1) / min_chunks;
     int nsplit = want < 1 ? 1 : (want > max_split ? (max_split < 1 ? 1 : max_split) : want);
     int cps = (total_chunks + nsplit - 1) / nsplit;
     nsplit = (total_chunks + cps - 1) / cps;
