@@ -180,15 +180,17 @@ def main():
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
             tk = tj.get('conv_kernel<128, 2, 2, false>')
             if tk and B == PER_GPU_BATCH and S == IMAGE_SIZE:
-                traffic = dict(bytes_per_launch=round((tk['fetch_MB_per_launch'] + tk['write_MB_per_launch']) * 1e6),
-                               source='profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, '
-                                      'FETCH_SIZE x2 gfx950 correction; fabric-side requests, Infinity-Cache hits included)')
+                traffic = round((tk['fetch_MB_per_launch'] + tk['write_MB_per_launch']) * 1e6)   # bytes per launch
         except (OSError, ValueError, KeyError):
             pass
+        traffic_source = None if traffic is None else (
+            'profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 '
+            '(gfx950 correction); fabric-side requests, Infinity-Cache hits included')
         if dom and dom['ms'] > 0:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
             roofline = dict(bound='mfma', achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                            frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, kernel=DOMINANT,
+                            frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
+                            kernel=DOMINANT,
                             algorithmic_bytes_per_launch=round(dom['bytes'] / dom['launches']),
                             mode='exclusive: instrumented steps run with fv_set_overlap(0)',
                             launches_per_step=dom['launches'] // max(args.profile_steps, 1),

@@ -3,8 +3,12 @@ UCCS-format training sequence (reference face_detection.py:75-310), plus a synth
 dataset generator (the real UCCS set is download-only and unavailable offline).
 
 This is CPU code in the reference too (Keras `Sequence` workers); it is not part of the device
-hot path.  Pixel resampling uses a bicubic (a = -0.75, OpenCV INTER_CUBIC's kernel) restatement;
-its pixel values are "parity unpinned" against cv2 (absent here) -- geometry is pinned exactly."""
+hot path.  FaceDetector itself letterboxes on the device (`fv_letterbox` via
+`TrainingSequence.get_raw` / `postproc.letterbox_device`); `letterbox()` / `__getitem__` below
+keep the reference's `Sequence[i] -> ({'input1': ...}, {'output': ...})` contract for callers
+that want host arrays.  Pixel resampling uses a bicubic (a = -0.75, OpenCV INTER_CUBIC's kernel)
+restatement; its pixel values are "parity unpinned" against cv2 (absent here) -- geometry is
+pinned exactly."""
 import os
 
 import numpy as np
