@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=1)
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-overlap', action='store_true', help='serialise wgrad on the main stream (A/B aid)')
+    ap.add_argument('--no-tail-split', action='store_true', help='conv launches without the tail split (A/B aid)')
     ap.add_argument('--no-detect', action='store_true', help='skip the detect-path measurement (PMC passes)')
     return ap.parse_args()
 
@@ -127,6 +128,8 @@ def main():
     eng.init_synthetic(seed=7)                      # identical weights on every rank
     if args.no_overlap:
         eng.ctx.set_overlap(False)
+    if args.no_tail_split:
+        eng.ctx.set_tail_split(False)
     trainer = DataParallelTrainer(eng, world_size=world, rank=rank)  # inits RCCL when world > 1
     B, S = args.batch, args.image_size
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)

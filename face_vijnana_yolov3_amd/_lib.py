@@ -63,6 +63,7 @@ def _declare(L):
     sig = {
         'fv_set_overlap': (i32, [vp, i32]),
         'fv_set_conv_dma': (i32, [vp, i32]),
+        'fv_set_tail_split': (i32, [vp, i32]),
         'fv_profile_enable': (i32, [vp, i32]),
         'fv_profile_collect': (i32, [vp, ctypes.POINTER(ProfileRec), i32, ctypes.POINTER(i32)]),
         'fv_num_layers': (i32, []),
@@ -133,6 +134,9 @@ class Context:
 
     def set_conv_dma(self, on):
         self.check(lib().fv_set_conv_dma(self._h, 1 if on else 0), 'fv_set_conv_dma')
+
+    def set_tail_split(self, on):
+        self.check(lib().fv_set_tail_split(self._h, 1 if on else 0), 'fv_set_tail_split')
 
     def profile(self, on):
         self.check(lib().fv_profile_enable(self._h, 1 if on else 0), 'fv_profile_enable')

@@ -59,6 +59,12 @@ int fv_set_conv_dma(fv_ctx* ctx, int on) {
     return FV_OK;
 }
 
+int fv_set_tail_split(fv_ctx* ctx, int on) {
+    if (!ctx) return FV_ERR_INVALID;
+    ctx->tail_split = on != 0;
+    return FV_OK;
+}
+
 int fv_profile_enable(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;
     ctx->prof_on = on != 0;

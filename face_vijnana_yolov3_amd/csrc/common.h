@@ -26,6 +26,11 @@ struct fv_ctx {
     bool conv_dma = false;   // fv_set_conv_dma: LDS-DMA operand staging variant of the conv kernel
     hipStream_t side = nullptr;
     hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr};
+    // scratch for the conv tail split (conv.h); lent by the network-level entry points out of the
+    // caller's workspace for the duration of one call, NULL otherwise
+    float* tail_slab = nullptr;
+    long long tail_slab_floats = 0;
+    bool tail_split = true;
     ~fv_ctx();
 };
 

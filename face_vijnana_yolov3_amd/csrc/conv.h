@@ -36,6 +36,9 @@ struct FvConvArgs {
     float leaky;
     int nclass;   // 1, or 4 for stride-2 data-gradient
     double alg_flops;  // algorithmic 2*MAC of this launch (profiling only)
+    int tail_f;        // >1: tail split active (set by the launcher): tiles >= tail_full are cut into tail_f K-slices
+    int tail_full;
+    float* tail_slab;  // [tail tiles * tail_f][128][BN] raw partial tiles
     int ksplit;        // >1: blockIdx.y owns a slice of the K steps and stores its raw partial to out + y*split_stride
     long long split_stride;
     int oph[4], opw[4];
@@ -46,6 +49,9 @@ struct FvConvArgs {
 int fv_conv_mtiles(int M, int Nout);
 // K-split factor the small-M inference path uses for a problem (1 = no split).
 int fv_conv_choose_ksplit(int M, int Nout, int ksteps);
+// Tail split plan for a launch (M rows, Nout channels, ksteps K steps): slices per tail tile (1 = off),
+// number of whole tiles, and the floats of slab scratch it needs.
+void fv_conv_tail_plan(int M, int Nout, int ksteps, int* tail_f, int* tail_full, long long* slab_floats);
 int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a);
 
 // Weight gradient:  dw[n][wslot[t]][c] += sum_{b,oh,ow} dy[b,oh,ow,n] * x[b, oh*is+dh[t], ow*is+dw[t], c]

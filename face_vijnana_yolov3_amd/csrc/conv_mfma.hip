@@ -53,7 +53,14 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
     const FvTaps& taps = a.taps[cls];
 
     const int NT = (a.Nout + BN - 1) / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    // Tail split (speed only): the first tail_full tiles are computed whole; every remaining tile is cut
+    // into tail_f K-slices, one workgroup each, dispatched after the whole tiles.  A slice stores its raw
+    // partial tile to tail_slab and conv_tail_fixup_kernel adds the slices in fixed order and applies the
+    // epilogue -- so the last, partly filled round of workgroups is divided among all CUs.
+    const bool tail_part = a.tail_f > 1 && (int)blockIdx.x >= a.tail_full;
+    const int tail_q = tail_part ? (int)blockIdx.x - a.tail_full : 0;
+    const int tile = a.tail_f > 1 ? (tail_part ? a.tail_full + tail_q / a.tail_f : xcd_remap(blockIdx.x, a.tail_full))
+                                  : xcd_remap(blockIdx.x, gridDim.x);
     const int mt = tile / NT, nt = tile - mt * NT;
     const int m0 = mt * BM, n0 = nt * BN;
     const int HWl = a.Hl * a.Wl;
@@ -159,9 +166,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
 
         const int cpk = a.Cin / BK;
         const int nk = taps.n * cpk;
-        // split-K (small-M inference): this block owns K steps [s_begin, s_end)
-        const int per = (nk + a.ksplit - 1) / a.ksplit;
-        const int s_begin = blockIdx.y * per;
+        // split-K (small-M inference: blockIdx.y; tail split: K-slice of a tail tile): this block
+        // owns K steps [s_begin, s_end)
+        const int nslice = tail_part ? a.tail_f : a.ksplit;
+        const int per = (nk + nslice - 1) / nslice;
+        const int s_begin = (tail_part ? tail_q % a.tail_f : (int)blockIdx.y) * per;
         const int s_end = min(nk, s_begin + per);
         u32x4 ra[4], rb[BL];
         unsigned a_off[4];
@@ -246,6 +255,23 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
 
     // ------------------------------------------------------------------ epilogue
     const int half = lane >> 5, lc = lane & 31;
+    if (tail_part) {
+        // K-slice of a tail tile: raw partial tile, tile-local [BM][BN] layout, to its slab
+        float* Cs = smem;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Cs[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BN + wn * WTN + j * 32 + lc] = acc[i][j][r];
+        __syncthreads();
+        float4* dst = reinterpret_cast<float4*>(a.tail_slab + (size_t)tail_q * (BM * BN));
+#pragma unroll
+        for (int p = 0; p < BM * BN / 4 / 256; ++p) dst[tid + 256 * p] = reinterpret_cast<const float4*>(Cs)[tid + 256 * p];
+        return;
+    }
     if (a.epi & FV_EPI_STATS) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -331,6 +357,76 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
                     a.out[(size_t)blockIdx.y * a.split_stride + off + n] = v;
                 }
             }
+    }
+}
+
+// Fix-up of the tail split: one workgroup per tail tile adds its tail_f raw K-slices in slice order
+// (deterministic), then does what the conv epilogue would have done: per-tile column sums / sums of
+// squares (training BN) and the affine / LeakyReLU / residual store.  HBM-bound, (tail_f + 1) tiles of
+// traffic per tail tile.
+template <int BN>
+__global__ __launch_bounds__(256) void conv_tail_fixup_kernel(const FvConvArgs a) {
+    __shared__ int rowoff[BM];
+    __shared__ float red[2][8][BN];
+    const int tid = threadIdx.x;
+    const int NT = (a.Nout + BN - 1) / BN;
+    const int tile = a.tail_full + blockIdx.x;
+    const int mt = tile / NT, nt = tile - mt * NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int HWl = a.Hl * a.Wl;
+    if (tid < BM) {
+        int m = m0 + tid, off = -1;
+        if (m < a.M) {
+            int b = m / HWl, rem = m - b * HWl, oh = rem / a.Wl, ow = rem - oh * a.Wl;
+            off = ((b * a.Hout + oh * a.os + a.oph[0]) * a.Wout + ow * a.os + a.opw[0]) * a.Nout;
+        }
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+    constexpr int C4 = BN / 4;                 // float4 pieces per tile row; 256 % C4 == 0, so a thread keeps its columns
+    const int c4 = (tid % C4) * 4, rl = tid / C4;
+    const int n = n0 + c4;
+    const float4* slab = reinterpret_cast<const float4*>(a.tail_slab + (size_t)blockIdx.x * a.tail_f * (BM * BN));
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
+#pragma unroll 4
+    for (int p = 0; p < BM * C4 / 256; ++p) {
+        const int f = tid + 256 * p, row = f / C4;
+        float4 v = slab[f];
+        for (int k = 1; k < a.tail_f; ++k) {
+            const float4 u = slab[(size_t)k * (BM * BN / 4) + f];
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+        cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
+        const int off = rowoff[row];
+        if (off >= 0 && n < a.Nout) {
+            if (a.epi & FV_EPI_AFFINE) {
+                if (a.scale) { const float4 s = *reinterpret_cast<const float4*>(a.scale + n); v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w; }
+                if (a.shift) { const float4 s = *reinterpret_cast<const float4*>(a.shift + n); v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+            }
+            if (a.epi & FV_EPI_LEAKY) {
+                v.x = v.x > 0.f ? v.x : v.x * a.leaky; v.y = v.y > 0.f ? v.y : v.y * a.leaky;
+                v.z = v.z > 0.f ? v.z : v.z * a.leaky; v.w = v.w > 0.f ? v.w : v.w * a.leaky;
+            }
+            if (a.epi & FV_EPI_ADD) {
+                const float4 s = *reinterpret_cast<const float4*>(a.addend + off + n);
+                v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+            }
+            *reinterpret_cast<float4*>(a.out + off + n) = v;
+        }
+    }
+    if (a.epi & FV_EPI_STATS) {
+        // rows outside the problem are zero in every slice, so they add nothing
+        constexpr int RL = 256 / C4;           // row lanes (8 for BN = 128)
+        *reinterpret_cast<float4*>(&red[0][rl % 8][c4]) = cs;   // RL <= 8 for BN >= 128; smaller BN never takes this path
+        *reinterpret_cast<float4*>(&red[1][rl % 8][c4]) = cq;
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Nout) {
+            float s = 0.f, q = 0.f;
+            for (int w = 0; w < RL; ++w) { s += red[0][w][tid]; q += red[1][w][tid]; }
+            a.psum[(size_t)mt * a.Nout + n0 + tid] = s;
+            a.psq[(size_t)mt * a.Nout + n0 + tid] = q;
+        }
     }
 }
 
@@ -545,11 +641,28 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
                           (double)a.M * a.nclass * a.Nout * ((a.epi & FV_EPI_ADD) ? 2 : 1)));
     FvConvArgs b = a;
     if (b.ksplit < 1) b.ksplit = 1;
+    b.tail_f = 1; b.tail_full = 0; b.tail_slab = nullptr;
     if constexpr (!G) {
         if (ctx->conv_dma) {   // measured neutral against the register-staged kernel; opt-in
             hipLaunchKernelGGL((conv_kernel_dma<BN, WM_, WN_>), grid, dim3(256), 0, ctx->stream, b);
             FV_LAUNCH_CHECK(ctx);
             return FV_OK;
+        }
+    }
+    if constexpr (!G && BN == 128) {
+        // tail split: only with caller scratch (network-level calls), whole-lattice launches, 16-byte rows
+        if (ctx->tail_slab && b.ksplit == 1 && a.nclass == 1 && (a.Nout & 3) == 0) {
+            int tf = 1, full = 0; long long need = 0;
+            fv_conv_tail_plan(a.M, a.Nout, a.taps[0].n * (a.Cin / BK), &tf, &full, &need);
+            if (tf > 1 && need <= ctx->tail_slab_floats) {
+                b.tail_f = tf; b.tail_full = full; b.tail_slab = ctx->tail_slab;
+                const int R = MT * NT - full;
+                hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G>), dim3(full + R * tf, 1, 1), dim3(256), 0, ctx->stream, b);
+                FV_LAUNCH_CHECK(ctx);
+                hipLaunchKernelGGL((conv_tail_fixup_kernel<BN>), dim3(R), dim3(256), 0, ctx->stream, b);
+                FV_LAUNCH_CHECK(ctx);
+                return FV_OK;
+            }
         }
     }
     hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G>), grid, dim3(256), 0, ctx->stream, b);
@@ -568,6 +681,27 @@ int fv_conv_choose_ksplit(int M, int Nout, int ksteps) {
     int want = (512 + tiles - 1) / tiles, cap = ksteps / 4;
     int ks = want < cap ? want : cap;
     return ks < 1 ? 1 : ks;
+}
+
+void fv_conv_tail_plan(int M, int Nout, int ksteps, int* tail_f, int* tail_full, long long* slab_floats) {
+    *tail_f = 1; *tail_full = 0; *slab_floats = 0;
+    if (Nout <= 64 || (Nout & 3)) return;                        // 128-wide tiles only
+    const int T = ((M + BM - 1) / BM) * ((Nout + 127) / 128);
+    const int slots = 512;                                       // 2 workgroups x 256 CUs
+    const int full = (T / slots) * slots, R = T - full;
+    if (R == 0 || R > 448) return;                               // last round (nearly) full already
+    // cost model in microseconds, from the measured block timeline: a round of co-resident tiles takes
+    // 13.6 + 3.25 us per K step; the fix-up moves (f + 1) tiles of 64 KiB per tail tile at ~4.5 TB/s
+    const double round_us = 13.6 + 3.25 * ksteps;
+    double best = ((R + slots - 1) / slots) * round_us;
+    int best_f = 1;
+    for (int f = 2; f <= 8 && ksteps / f >= 4; ++f) {
+        const int per = (ksteps + f - 1) / f;
+        const double slice_us = 13.6 + 3.25 * per;
+        const double c = ((R * f + slots - 1) / slots) * slice_us + 6.0 + (double)R * (f + 1) * 65536.0 / 4.5e6;
+        if (c < best * 0.95) { best = c; best_f = f; }
+    }
+    if (best_f > 1) { *tail_f = best_f; *tail_full = full; *slab_floats = (long long)R * best_f * BM * 128; }
 }
 
 int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {

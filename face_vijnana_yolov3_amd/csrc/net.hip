@@ -69,8 +69,18 @@ struct Carver {
 struct Plan {
     int B, S, nl;
     std::vector<float*> z, a, mean, invstd, scale, shift, wt;
-    float *psum, *psq, *pdb, *pdg, *w0p, *yhat, *dyp, *G[3], *D[2], *loss, *slab;
+    float *psum, *psq, *pdb, *pdg, *w0p, *yhat, *dyp, *G[3], *D[2], *loss, *slab, *tail;
+    size_t tail_floats;
     size_t bytes;
+};
+
+// Lends the plan's tail-split scratch to the conv launcher for the duration of one network call.
+struct TailLend {
+    fv_ctx* ctx;
+    TailLend(fv_ctx* c, const Plan& p) : ctx(c) {
+        if (c->tail_split && p.tail) { c->tail_slab = p.tail; c->tail_slab_floats = (long long)p.tail_floats; }
+    }
+    ~TailLend() { ctx->tail_slab = nullptr; ctx->tail_slab_floats = 0; }
 };
 
 // Carve the workspace (base == NULL: size query only).
@@ -135,6 +145,23 @@ Plan make_plan(void* base, int B, int S, bool training) {
         }
         p.slab = max_slab ? c.take(max_slab) : nullptr;
     }
+    {   // tail-split scratch: largest need over the forward and (training) stride-1 data-gradient launches
+        long long need = 0;
+        for (int l = 1; l < p.nl; ++l) {
+            const auto& d = N.L[l];
+            const int Hi = S / d.in_div, Ho = Hi / d.stride;
+            int tf, full; long long n;
+            fv_conv_tail_plan(B * Ho * Ho, d.cout, d.ksize * d.ksize * d.cin / 32, &tf, &full, &n);
+            if (n > need) need = n;
+            if (training && d.stride == 1) {
+                const int cp = d.has_bn ? d.cout : HEAD_PAD;
+                fv_conv_tail_plan(B * Hi * Hi, d.cin, d.ksize * d.ksize * cp / 32, &tf, &full, &n);
+                if (n > need) need = n;
+            }
+        }
+        p.tail_floats = (size_t)need;
+        p.tail = need ? c.take((size_t)need) : nullptr;
+    }
     p.bytes = c.off;
     return p;
 }
@@ -170,6 +197,7 @@ int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, co
     if (int rc = check_shape(ctx, batch, image_size)) return rc;
     Plan p = make_plan(workspace, batch, image_size, false);
     if (p.bytes > workspace_bytes) return fv_fail(ctx, FV_ERR_WORKSPACE, "forward_infer: workspace %zu < %zu bytes", workspace_bytes, p.bytes);
+    TailLend lend(ctx, p);
     const Net& N = net();
     const int nb = p.nl - 1;
     {   // fold the moving statistics of all 52 BN layers into scale/shift with one launch
@@ -231,6 +259,7 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
     if (int rc = check_shape(ctx, batch, image_size)) return rc;
     Plan p = make_plan(workspace, batch, image_size, true);
     if (p.bytes > workspace_bytes) return fv_fail(ctx, FV_ERR_WORKSPACE, "train_step: workspace %zu < %zu bytes", workspace_bytes, p.bytes);
+    TailLend lend(ctx, p);
     const Net& N = net();
     const int nb = p.nl - 1;
     const int S = image_size;

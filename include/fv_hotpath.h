@@ -51,6 +51,12 @@ int fv_set_overlap(fv_ctx* ctx, int on);
 /* Conv operand staging through LDS-DMA (buffer_load ... lds, XOR-swizzled unpadded LDS image)
  * instead of VGPR staging.  Bit-identical results; measured neutral on MI355X (default: off). */
 int fv_set_conv_dma(fv_ctx* ctx, int on);
+/* Tail split of the conv launches inside fv_train_step / fv_forward_infer: when the 128x128 output
+ * tiles of a layer do not fill a whole number of rounds of the 512 resident workgroup slots, the
+ * tiles of the last partial round are cut into K slices (one workgroup each) whose partial tiles a
+ * fix-up kernel sums in fixed slice order before the epilogue.  Deterministic; changes only the
+ * fp32 summation order of those tiles (default: on). */
+int fv_set_tail_split(fv_ctx* ctx, int on);
 
 /* ------------------------------------------------------------------ per-kernel timing
  * Measurement aid with no counterpart in the reference (it has no profiler hooks):

@@ -173,6 +173,45 @@ def test_side_stream_overlap_equals_serial(eng):
     assert d <= 1e-5 * res[1][1].abs().max().item() + 1e-9, d
 
 
+def test_tail_split_on_off(eng):
+    """fv_set_tail_split: tiles of the last partial round cut into K slices + fix-up kernel.  Only the
+    fp32 summation order of those tiles changes: inference outputs agree to rounding, both settings meet
+    the oracle bound in training, and each setting is run-to-run deterministic in the forward pass."""
+    from oracle import net_oracle as no
+    B, S = 6, 128
+    p64, s64, x, yt = _setup(17, B, S)
+    y64, _ = no.forward(p64, s64, x, training=False)
+    y32, _ = no.forward(p64.float(), s64.float(), x.float(), training=False)
+    l64, g64, ns64 = no.train_step_grads(p64, s64, x, yt)
+    l32, g32, ns32 = no.train_step_grads(p64.float(), s64.float(), x.float(), yt.float())
+    gn32 = (g32.double() - g64).norm().item() / g64.norm().item()
+    ys, sts = [], []
+    try:
+        for on in (True, False):
+            eng.ctx.set_tail_split(on)
+            eng.set_params(p64.float(), s64.float())
+            y = eng.predict_device(x.float()).clone()
+            y2 = eng.predict_device(x.float()).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(y, y2)
+            _within(y.cpu(), y64, y32, 'forward_infer tail_split=%s' % on)
+            ys.append(y)
+            eng.m = eng.v = eng.grads = None
+            loss = eng.forward_backward(x.float(), yt.float())
+            torch.cuda.synchronize()
+            assert abs(loss.item() - l64.item()) <= 4 * abs(l32.item() - l64.item()) + 1e-6 * abs(l64.item())
+            _within(eng.state.cpu(), ns64, ns32, 'bn moving state tail_split=%s' % on)
+            sts.append(eng.state.clone())
+            gn = (eng.grads.cpu().double() - g64).norm().item() / g64.norm().item()
+            assert gn <= 6 * gn32 + 1e-5, (on, gn, gn32)
+    finally:
+        eng.ctx.set_tail_split(True)
+    d = (ys[0] - ys[1]).abs().max().item()
+    assert d <= 2e-5 * ys[1].abs().max().item(), d
+    # the split really ran at this size (training forward: 48..192-tile layers): batch statistics differ in rounding
+    assert (sts[0] != sts[1]).any()
+
+
 def test_config5_608_grid19(eng):
     """BASELINE config 5: image_size 608 (grid 19 = the build's generalisation of the reference's
     hard-coded CELL_SIZE=13).  One image: inference forward and a train step against the
