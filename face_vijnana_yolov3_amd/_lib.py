@@ -64,6 +64,7 @@ def _declare(L):
         'fv_set_overlap': (i32, [vp, i32]),
         'fv_set_conv_dma': (i32, [vp, i32]),
         'fv_set_tail_split': (i32, [vp, i32]),
+        'fv_set_conv_scratch': (i32, [vp, vp, sz]),
         'fv_profile_enable': (i32, [vp, i32]),
         'fv_profile_collect': (i32, [vp, ctypes.POINTER(ProfileRec), i32, ctypes.POINTER(i32)]),
         'fv_num_layers': (i32, []),
@@ -137,6 +138,15 @@ class Context:
 
     def set_tail_split(self, on):
         self.check(lib().fv_set_tail_split(self._h, 1 if on else 0), 'fv_set_tail_split')
+
+    def set_conv_scratch(self, tensor):
+        """Lend device scratch (a torch tensor, kept alive here) to the per-operator conv calls."""
+        self._conv_scratch = tensor
+        if tensor is None:
+            self.check(lib().fv_set_conv_scratch(self._h, c_void_p(None), 0), 'fv_set_conv_scratch')
+        else:
+            self.check(lib().fv_set_conv_scratch(self._h, c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size()),
+                       'fv_set_conv_scratch')
 
     def profile(self, on):
         self.check(lib().fv_profile_enable(self._h, 1 if on else 0), 'fv_profile_enable')

@@ -65,6 +65,13 @@ int fv_set_tail_split(fv_ctx* ctx, int on) {
     return FV_OK;
 }
 
+int fv_set_conv_scratch(fv_ctx* ctx, void* buf, size_t bytes) {
+    if (!ctx) return FV_ERR_INVALID;
+    ctx->tail_slab = buf ? (float*)buf : nullptr;
+    ctx->tail_slab_floats = buf ? (long long)(bytes / sizeof(float)) : 0;
+    return FV_OK;
+}
+
 int fv_profile_enable(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;
     ctx->prof_on = on != 0;

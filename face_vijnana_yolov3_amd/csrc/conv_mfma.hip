@@ -173,6 +173,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
         const int s_begin = (tail_part ? tail_q % a.tail_f : (int)blockIdx.y) * per;
         const int s_end = min(nk, s_begin + per);
         u32x4 ra[4], rb[BL];
+#if defined(FV_ABLATE_NOLOAD)
+        for (int p = 0; p < 4; ++p) ra[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
+        for (int p = 0; p < BL; ++p) rb[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
+#endif
         unsigned a_off[4];
         int t = s_begin / cpk, ci = s_begin - t * cpk;
         auto set_tap = [&](int tp) {
@@ -185,10 +189,18 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
             }
         };
         auto load = [&]() {
+#if defined(FV_ABLATE_NOLOAD)
+            return;
+#endif
+#if defined(FV_ABLATE_SAMEADDR)
+            const int c0b = 0;
+            const int wofs = 0;
+#else
             const int c0b = ci * BK * 4;
+            const int wofs = (taps.wslot[t] * a.Cin) * 4 + c0b;
+#endif
 #pragma unroll
             for (int p = 0; p < 4; ++p) ra[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, a_off[p], c0b, 0);
-            const int wofs = (taps.wslot[t] * a.Cin) * 4 + c0b;
 #pragma unroll
             for (int p = 0; p < BL; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_row[p], wofs, 0);
         };
@@ -201,7 +213,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
                 *reinterpret_cast<u32x4*>(&Bs[buf][((tid >> 3) + 32 * p) * LDT + col4]) = rb[p];
         };
         auto advance = [&]() {
+#if defined(FV_ABLATE_SAMEADDR)
+            if (++ci == cpk) { ci = 0; ++t; }
+#else
             if (++ci == cpk) { ci = 0; ++t; if (t < taps.n) set_tap(t); }
+#endif
         };
         // fragment double-buffering: the LDS reads of K-chunk c+1 are issued before the MFMAs of
         // chunk c, and the next tile is staged into the other LDS buffer while chunks 2-3 compute
@@ -240,14 +256,24 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
             const bool more = s + 1 < s_end;
             if (more) load();
             float4 af0[MB], bf0[NB], af1[MB], bf1[NB];
+            // sched_barrier pins this order: left alone, the scheduler sinks the reads of chunks 2-3
+            // behind 31 of the first 32 MFMAs and then waits for them (and the stage writes) with the
+            // matrix pipe empty
             readfrag(As[cur], Bs[cur], 0, af0, bf0);
             readfrag(As[cur], Bs[cur], 1, af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
             readfrag(As[cur], Bs[cur], 2, af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
             readfrag(As[cur], Bs[cur], 3, af1, bf1);
-            if (more) { stage(cur ^ 1); advance(); }
+            __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) { stage(cur ^ 1); advance(); }
+            __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(af1, bf1);
             __syncthreads();
         }
@@ -365,9 +391,13 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
 // squares (training BN) and the affine / LeakyReLU / residual store.  HBM-bound, (tail_f + 1) tiles of
 // traffic per tail tile.
 template <int BN>
-__global__ __launch_bounds__(256) void conv_tail_fixup_kernel(const FvConvArgs a) {
+__global__ __launch_bounds__(1024) void conv_tail_fixup_kernel(const FvConvArgs a) {
+    constexpr int NTH = 1024;
+    constexpr int C4 = BN / 4;                 // float4 pieces per tile row; NTH % C4 == 0, so a thread keeps its columns
+    constexpr int RL = NTH / C4;               // rows per pass (32 for BN = 128)
+    static_assert(NTH % C4 == 0 && (BM * C4) % NTH == 0, "fix-up tiling");
     __shared__ int rowoff[BM];
-    __shared__ float red[2][8][BN];
+    __shared__ float red[2][RL][BN];
     const int tid = threadIdx.x;
     const int NT = (a.Nout + BN - 1) / BN;
     const int tile = a.tail_full + blockIdx.x;
@@ -383,14 +413,13 @@ __global__ __launch_bounds__(256) void conv_tail_fixup_kernel(const FvConvArgs a
         rowoff[tid] = off;
     }
     __syncthreads();
-    constexpr int C4 = BN / 4;                 // float4 pieces per tile row; 256 % C4 == 0, so a thread keeps its columns
     const int c4 = (tid % C4) * 4, rl = tid / C4;
     const int n = n0 + c4;
     const float4* slab = reinterpret_cast<const float4*>(a.tail_slab + (size_t)blockIdx.x * a.tail_f * (BM * BN));
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
-#pragma unroll 4
-    for (int p = 0; p < BM * C4 / 256; ++p) {
-        const int f = tid + 256 * p, row = f / C4;
+#pragma unroll
+    for (int p = 0; p < BM * C4 / NTH; ++p) {
+        const int f = tid + NTH * p, row = f / C4;
         float4 v = slab[f];
         for (int k = 1; k < a.tail_f; ++k) {
             const float4 u = slab[(size_t)k * (BM * BN / 4) + f];
@@ -417,12 +446,12 @@ __global__ __launch_bounds__(256) void conv_tail_fixup_kernel(const FvConvArgs a
     }
     if (a.epi & FV_EPI_STATS) {
         // rows outside the problem are zero in every slice, so they add nothing
-        constexpr int RL = 256 / C4;           // row lanes (8 for BN = 128)
-        *reinterpret_cast<float4*>(&red[0][rl % 8][c4]) = cs;   // RL <= 8 for BN >= 128; smaller BN never takes this path
-        *reinterpret_cast<float4*>(&red[1][rl % 8][c4]) = cq;
+        *reinterpret_cast<float4*>(&red[0][rl][c4]) = cs;
+        *reinterpret_cast<float4*>(&red[1][rl][c4]) = cq;
         __syncthreads();
         if (tid < BN && n0 + tid < a.Nout) {
             float s = 0.f, q = 0.f;
+#pragma unroll
             for (int w = 0; w < RL; ++w) { s += red[0][w][tid]; q += red[1][w][tid]; }
             a.psum[(size_t)mt * a.Nout + n0 + tid] = s;
             a.psq[(size_t)mt * a.Nout + n0 + tid] = q;
@@ -651,7 +680,7 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
     }
     if constexpr (!G && BN == 128) {
         // tail split: only with caller scratch (network-level calls), whole-lattice launches, 16-byte rows
-        if (ctx->tail_slab && b.ksplit == 1 && a.nclass == 1 && (a.Nout & 3) == 0) {
+        if (ctx->tail_split && ctx->tail_slab && b.ksplit == 1 && a.nclass == 1 && (a.Nout & 3) == 0) {
             int tf = 1, full = 0; long long need = 0;
             fv_conv_tail_plan(a.M, a.Nout, a.taps[0].n * (a.Cin / BK), &tf, &full, &need);
             if (tf > 1 && need <= ctx->tail_slab_floats) {
@@ -659,7 +688,7 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
                 const int R = MT * NT - full;
                 hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G>), dim3(full + R * tf, 1, 1), dim3(256), 0, ctx->stream, b);
                 FV_LAUNCH_CHECK(ctx);
-                hipLaunchKernelGGL((conv_tail_fixup_kernel<BN>), dim3(R), dim3(256), 0, ctx->stream, b);
+                hipLaunchKernelGGL((conv_tail_fixup_kernel<BN>), dim3(R), dim3(1024), 0, ctx->stream, b);
                 FV_LAUNCH_CHECK(ctx);
                 return FV_OK;
             }
@@ -689,19 +718,25 @@ void fv_conv_tail_plan(int M, int Nout, int ksteps, int* tail_f, int* tail_full,
     const int T = ((M + BM - 1) / BM) * ((Nout + 127) / 128);
     const int slots = 512;                                       // 2 workgroups x 256 CUs
     const int full = (T / slots) * slots, R = T - full;
-    if (R == 0 || R > 448) return;                               // last round (nearly) full already
-    // cost model in microseconds, from the measured block timeline: a round of co-resident tiles takes
-    // 13.6 + 3.25 us per K step; the fix-up moves (f + 1) tiles of 64 KiB per tail tile at ~4.5 TB/s
-    const double round_us = 13.6 + 3.25 * ksteps;
-    double best = ((R + slots - 1) / slots) * round_us;
+    if (R == 0) return;
+    // Cost model in microseconds, fitted to per-layer timings on MI355X (tools/layer_bench.py): a K step
+    // costs 3.8 us when two workgroups share a CU and 2.25 us when a workgroup has the CU to itself, a
+    // round of workgroups carries ~8 us of prologue + epilogue; the fix-up kernel is one more launch
+    // (~17 us with its gap) and moves (f + 1) tiles of 64 KiB per tail tile.
+    auto round_us = [](int nwg, int steps) { return (nwg <= 256 ? 2.25 : 3.8) * steps + 8.0; };
+    const double unsplit = round_us(R, ksteps);
+    double best = unsplit;
     int best_f = 1;
     for (int f = 2; f <= 8 && ksteps / f >= 4; ++f) {
-        const int per = (ksteps + f - 1) / f;
-        const double slice_us = 13.6 + 3.25 * per;
-        const double c = ((R * f + slots - 1) / slots) * slice_us + 6.0 + (double)R * (f + 1) * 65536.0 / 4.5e6;
-        if (c < best * 0.95) { best = c; best_f = f; }
+        const int per = (ksteps + f - 1) / f, P = R * f;
+        if ((f - 1) * per >= ksteps) continue;                   // would leave an empty slice
+        double c = (P / slots) * round_us(slots, per) + (P % slots ? round_us(P % slots, per) : 0.0);
+        c += 17.0 + 15.0 + (double)R * (f + 1) * 65536.0 / 4.5e6;
+        if (c < best) { best = c; best_f = f; }
     }
-    if (best_f > 1) { *tail_f = best_f; *tail_full = full; *slab_floats = (long long)R * best_f * BM * 128; }
+    if (best_f > 1 && unsplit - best >= 10.0 && best <= 0.95 * unsplit) {
+        *tail_f = best_f; *tail_full = full; *slab_floats = (long long)R * best_f * BM * 128;
+    }
 }
 
 int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {

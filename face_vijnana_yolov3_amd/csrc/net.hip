@@ -77,10 +77,12 @@ struct Plan {
 // Lends the plan's tail-split scratch to the conv launcher for the duration of one network call.
 struct TailLend {
     fv_ctx* ctx;
-    TailLend(fv_ctx* c, const Plan& p) : ctx(c) {
+    float* prev; long long prev_floats;
+    TailLend(fv_ctx* c, const Plan& p) : ctx(c), prev(c->tail_slab), prev_floats(c->tail_slab_floats) {
+        c->tail_slab = nullptr; c->tail_slab_floats = 0;
         if (c->tail_split && p.tail) { c->tail_slab = p.tail; c->tail_slab_floats = (long long)p.tail_floats; }
     }
-    ~TailLend() { ctx->tail_slab = nullptr; ctx->tail_slab_floats = 0; }
+    ~TailLend() { ctx->tail_slab = prev; ctx->tail_slab_floats = prev_floats; }
 };
 
 // Carve the workspace (base == NULL: size query only).

@@ -56,7 +56,9 @@ int fv_op_conv_dgrad(fv_ctx* ctx, const float* dy, const float* w_t, int B, int 
         a.Hl = H / 2; a.Wl = W / 2; a.os = 2; a.nclass = 4;
         for (int ph = 0; ph < 2; ++ph)
             for (int pw = 0; pw < 2; ++pw) {
-                int c = ph * 2 + pw;
+                // class = blockIdx.z, dispatched in ascending order: the 4-tap class (ph = pw = 1) goes
+                // first and the 1-tap class last, so the longest tiles are not left for the tail
+                int c = 3 - (ph * 2 + pw);
                 a.oph[c] = ph; a.opw[c] = pw;
                 FvTaps& t = a.taps[c];
                 t.n = 0;

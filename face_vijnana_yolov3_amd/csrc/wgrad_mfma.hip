@@ -10,8 +10,11 @@
 // consumed with conflict-free ds_read_b32 (32 consecutive dwords per lane half).
 //  * QUAD  (128x128 tile): 2x2 waves, each a 64x64 sub-tile over all 32 pixels of a chunk
 //  * split (32/64 tiles) : every wave owns the whole tile over its quarter of the pixel chunk
-//  * grid = (tiles x taps, K-splits); partial tiles are added with float atomics shaped as two
-//    128-byte row segments per wave instruction; the caller zeroes dw once per step
+//  * grid = tiles x taps x K-splits in one dimension, a K-split pinned to one XCD (its workgroups
+//    share the x / dy chunks in that L2); the split count fills whole rounds of the XCD's 64
+//    workgroup slots; partial tiles are added with float atomics shaped as two 128-byte row segments
+//    per wave instruction; the caller zeroes dw once per step
+//  * chunk loop: global loads one chunk ahead, LDS fragments one k-pair ahead (register double buffer)
 #include "conv.h"
 
 namespace {
@@ -21,7 +24,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KP = 32;  // pixels per chunk
 
 template <int TM, int TN, bool QUAD, bool GATHER>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int chunks_per_split, int ntap_eff) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int nsplit, int ntap_eff, int tiles_taps) {
     constexpr int LDA = TM + 4, LDB = TN + 4;  // +4 keeps 16-byte row alignment for the staged float4 writes
     constexpr int WTM = QUAD ? TM / 2 : TM, WTN = QUAD ? TN / 2 : TN;
     constexpr int MB = WTM / 32, NB = WTN / 32;
@@ -34,16 +37,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = QUAD ? (wave >> 1) : 0, wn = QUAD ? (wave & 1) : 0;
     const int NTc = GATHER ? 1 : a.Cin / TN;
-    int bid = blockIdx.x;
-    const int tp = bid % ntap_eff; bid /= ntap_eff;   // taps fastest: tap blocks of one tile share dy in L2
+    // Workgroup ids go round-robin over the 8 XCDs (one L2 each).  All (tile, tap) workgroups of one
+    // K-split read the same 32-pixel chunks of x and dy, so a split is pinned to one XCD: id = 8 j + xcd,
+    // split = 8 (j / tiles) + xcd -- its blocks then hit in that XCD's L2 instead of each going to the fabric.
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int split = (jx / tiles_taps) * 8 + xcd;
+    int bid = jx % tiles_taps;
+    const int tp = bid % ntap_eff; bid /= ntap_eff;   // taps fastest
     const int ct = bid % NTc, nt = bid / NTc;
     const int n0 = nt * TM, c0 = ct * TN;
     const int HWl = a.Hl * a.Wl;
     const int dh = GATHER ? 0 : a.taps.dh[tp], dw = GATHER ? 0 : a.taps.dw[tp];
 
     const int total_chunks = (a.M + KP - 1) / KP;
-    const int ch_begin = blockIdx.y * chunks_per_split;
-    const int ch_end = min(total_chunks, ch_begin + chunks_per_split);
+    // balanced partition of the chunks over the splits (sizes differ by at most one)
+    const int ch_begin = (int)((long long)split * total_chunks / nsplit);
+    const int ch_end = (int)((long long)(split + 1) * total_chunks / nsplit);
     if (ch_begin >= ch_end) return;
 
     f32x16 acc[MB][NB];
@@ -72,6 +81,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
         a_off[p] = (n0 + col < a.N) ? (unsigned)(n0 + col) * 4u : OOB;
     }
     int b_b[BL], b_oh[BL], b_ow[BL], b_m[BL], b_col[BL];
+    const int adv_b = KP / HWl, adv_h = (KP - adv_b * HWl) / a.Wl, adv_w = KP - adv_b * HWl - adv_h * a.Wl;
     if constexpr (!GATHER) {
 #pragma unroll
         for (int p = 0; p < BL; ++p) {
@@ -83,10 +93,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
         }
     }
     u32x4 ra[AL], rb[BL];
+#if defined(FV_ABLATE_NOLOAD)
+    for (int p = 0; p < AL; ++p) ra[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
+    for (int p = 0; p < BL; ++p) rb[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
+#endif
     auto load = [&]() {
+#if defined(FV_ABLATE_NOLOAD)
+        return;
+#endif
 #pragma unroll
         for (int p = 0; p < AL; ++p) {
-            unsigned off = (a_m[p] < a.M && a_off[p] != OOB) ? (unsigned)a_m[p] * (unsigned)a.Ndy * 4u + a_off[p] : OOB;
+            // a_off carries the OOB bit for channel groups outside N; rows past M get it here (no branches)
+            unsigned off = ((unsigned)a_m[p] * (unsigned)a.Ndy * 4u + a_off[p]) | (a_m[p] < a.M ? 0u : OOB);
+#if defined(FV_ABLATE_SAMEADDR)
+            off = a_off[p] != OOB ? (unsigned)(tid / (TM / 4)) * (unsigned)a.Ndy * 4u + a_off[p] : OOB;
+#endif
             ra[p] = __builtin_amdgcn_raw_buffer_load_b128(yr, off, 0, 0);
             a_m[p] += KP;
         }
@@ -113,13 +134,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
 #pragma unroll
             for (int p = 0; p < BL; ++p) {
                 int ih = b_oh[p] * a.is + dh, iw = b_ow[p] * a.is + dw;
-                bool ok = b_m[p] < a.M && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
-                unsigned off = ok ? (unsigned)(((b_b[p] * a.Hin + ih) * a.Win + iw) * a.Cin + c0 + b_col[p]) * 4u : OOB;
+                const bool ok = b_m[p] < a.M && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+                unsigned off = ((unsigned)(((b_b[p] * a.Hin + ih) * a.Win + iw) * a.Cin + c0 + b_col[p]) * 4u) | (ok ? 0u : OOB);
+#if defined(FV_ABLATE_SAMEADDR)
+                off = (unsigned)((tid / (TN / 4)) * a.Cin + c0 + b_col[p]) * 4u;
+#endif
                 rb[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
-                // advance this row by KP pixels
-                b_m[p] += KP; b_ow[p] += KP;
-                while (b_ow[p] >= a.Wl) { b_ow[p] -= a.Wl; ++b_oh[p]; }
-                while (b_oh[p] >= a.Hl) { b_oh[p] -= a.Hl; ++b_b[p]; }
+                // advance this row by KP pixels: branch-free carries (KP = adv_b images + adv_h rows + adv_w pixels)
+                b_m[p] += KP;
+                b_ow[p] += adv_w;
+                { const bool c = b_ow[p] >= a.Wl; b_ow[p] -= c ? a.Wl : 0; b_oh[p] += adv_h + (c ? 1 : 0); }
+                { const bool c = b_oh[p] >= a.Hl; b_oh[p] -= c ? a.Hl : 0; b_b[p] += adv_b + (c ? 1 : 0); }
             }
         }
     };
@@ -142,14 +167,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
     constexpr int KW = QUAD ? KP : KP / 4;  // pixels this wave consumes per chunk
     const int kbase = QUAD ? 0 : wave * KW;
     const int aoff = wm * WTM + (lane & 31), boff = wn * WTN + (lane & 31);
-    // one k-pair (2 pixels): lanes 0-31 take pixel k, lanes 32-63 pixel k+1
-    auto step = [&](const float* __restrict__ Asm, const float* __restrict__ Bsm, int kk) {
+    // one k-pair (2 pixels): lanes 0-31 take pixel k, lanes 32-63 pixel k+1.  Fragments are double
+    // buffered in registers: the LDS reads of pair i+1 are issued before the MFMAs of pair i.
+    auto readfrag = [&](const float* __restrict__ Asm, const float* __restrict__ Bsm, int kk, float (&af)[MB], float (&bf)[NB]) {
         const int k = kbase + kk + (lane >> 5);
-        float af[MB], bf[NB];
 #pragma unroll
         for (int i = 0; i < MB; ++i) af[i] = Asm[k * LDA + aoff + i * 32];
 #pragma unroll
         for (int j = 0; j < NB; ++j) bf[j] = Bsm[k * LDB + boff + j * 32];
+    };
+    auto mfma = [&](const float (&af)[MB], const float (&bf)[NB]) {
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -160,15 +187,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
     load();
     stage(0);
     __syncthreads();
+    constexpr int NP = KW / 2;   // k-pairs per chunk for this wave
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int cur = (ch - ch_begin) & 1;
         const bool more = ch + 1 < ch_end;
         if (more) load();
+        float af0[MB], bf0[NB], af1[MB], bf1[NB];
+        readfrag(As[cur], Bs[cur], 0, af0, bf0);
 #pragma unroll
-        for (int kk = 0; kk < KW / 2; kk += 2) step(As[cur], Bs[cur], kk);
-        if (more) stage(cur ^ 1);   // next tile lands in the other buffer while the second half computes
-#pragma unroll
-        for (int kk = KW / 2; kk < KW; kk += 2) step(As[cur], Bs[cur], kk);
+        for (int i = 0; i < NP; i += 2) {
+            // sched_barrier: keep the reads of the next pair ahead of this pair's MFMAs (the scheduler
+            // otherwise sinks them behind and waits lgkmcnt(0) in front of every MFMA group)
+            readfrag(As[cur], Bs[cur], 2 * (i + 1), af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(af0, bf0);
+            if (i == NP / 2) { if (more) stage(cur ^ 1); }   // next tile lands in the other buffer mid-chunk
+            if (i + 2 < NP) readfrag(As[cur], Bs[cur], 2 * (i + 2), af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(af1, bf1);
+        }
         __syncthreads();
     }
 
@@ -197,22 +234,31 @@ int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
     const int ntap = GATHER ? 1 : a.taps.n;
     const int tiles = ((a.N + TM - 1) / TM) * (GATHER ? 1 : a.Cin / TN) * ntap;
     const int total_chunks = (a.M + KP - 1) / KP;
-    // enough K-splits to fill the chip ~4 blocks deep, but at least 8 chunks of work per block
-    int want = (256 * 8 + tiles - 1) / tiles;
-    // every block pays a fixed epilogue (64 atomics per lane): at least 8 chunks of work per block,
-    // 16 for 1x1 kernels (few tiles, so all parallelism comes from the split; measured +12 %)
+    // K-splits come in groups of 8 (one per XCD, see the kernel).  Per XCD there are 64 workgroup slots
+    // (32 CUs x 2): pick the group count q whose q * tiles workgroups fill whole rounds of those slots,
+    // with enough chunks per workgroup to amortise its fixed cost (prologue + 64 atomics per lane, about
+    // 2.5 chunks' worth; at least 8 chunks, 16 for 1x1 kernels where all parallelism comes from the split).
     const int min_chunks = ntap == 1 ? 16 : 8;
-    int max_split = (total_chunks + min_chunks - 1) / min_chunks;
-    int nsplit = want < 1 ? 1 : (want > max_split ? (max_split < 1 ? 1 : max_split) : want);
-    int cps = (total_chunks + nsplit - 1) / nsplit;
-    nsplit = (total_chunks + cps - 1) / cps;
+    int qmax = total_chunks / (8 * min_chunks);
+    qmax = qmax < 1 ? 1 : (qmax > 64 ? 64 : qmax);
+    int best_q = 1;
+    double best = -1.0;
+    for (int q = 1; q <= qmax; ++q) {
+        const double r = q * tiles / 64.0, rounds = r <= 1.0 ? 1.0 : (double)(long long)(r + 0.999999);
+        const double ch = total_chunks / (8.0 * q);
+        const double score = (r / rounds) * ch / (ch + 2.5);
+        if (score > best * 1.005) { best = score; best_q = q; }
+    }
+    int nsplit = 8 * best_q;
+    if (nsplit > total_chunks) nsplit = total_chunks;   // tiny problems: empty splits return at once
     static const char* name = QUAD ? "wgrad_kernel<128,128,quad>"
                               : GATHER ? (TM == 64 ? "wgrad_kernel<64,32,gather>" : "wgrad_kernel<32,32,gather>")
                               : TM == 64 ? (TN == 64 ? "wgrad_kernel<64,64>" : "wgrad_kernel<64,32>")
                                          : (TN == 64 ? "wgrad_kernel<32,64>" : "wgrad_kernel<32,32>");
     FvProfScope ps(ctx, name, a.alg_flops,
                    4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.M * a.N + (double)a.N * a.Tw * a.Cin));
-    hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER>), dim3(tiles, nsplit), dim3(256), 0, ctx->stream, a, cps, ntap);
+    const int nsplit8 = (nsplit + 7) / 8 * 8;   // padded splits return at once (no chunks)
+    hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER>), dim3(tiles * nsplit8), dim3(256), 0, ctx->stream, a, nsplit, ntap, tiles);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }

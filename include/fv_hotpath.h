@@ -57,6 +57,11 @@ int fv_set_conv_dma(fv_ctx* ctx, int on);
  * fix-up kernel sums in fixed slice order before the epilogue.  Deterministic; changes only the
  * fp32 summation order of those tiles (default: on). */
 int fv_set_tail_split(fv_ctx* ctx, int on);
+/* The per-operator conv entry points (fv_conv2d_forward / fv_conv2d_dgrad) have no workspace
+ * argument; a caller that wants the tail split there lends device scratch here (NULL, 0 = none;
+ * 64 MiB covers every Darknet-53 shape at batch 40).  The buffer must stay valid until the calls that
+ * use it have completed on the stream.  fv_train_step / fv_forward_infer use their own workspace. */
+int fv_set_conv_scratch(fv_ctx* ctx, void* buf, size_t bytes);
 
 /* ------------------------------------------------------------------ per-kernel timing
  * Measurement aid with no counterpart in the reference (it has no profiler hooks):

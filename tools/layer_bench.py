@@ -17,7 +17,9 @@ from face_vijnana_yolov3_amd.engine import layer_table  # noqa: E402
 
 
 def timeit(fn, reps):
-    fn(); torch.cuda.synchronize()
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -32,8 +34,11 @@ def main():
     ap.add_argument('--size', type=int, default=416)
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--only', default='')
+    ap.add_argument('--scratch-mib', type=int, default=0, help='lend conv scratch (enables the tail split at op level)')
     a = ap.parse_args()
     ctx = Context(0)
+    if a.scratch_mib:
+        ctx.set_conv_scratch(torch.empty(a.scratch_mib << 20, dtype=torch.uint8, device='cuda'))
     seen = {}
     for d in layer_table():
         key = (d['ksize'], d['stride'], d['cin'], d['cout'], a.size // d['in_div'])
