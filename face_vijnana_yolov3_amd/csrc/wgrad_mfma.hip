@@ -24,7 +24,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KP = 32;  // pixels per chunk
 
 template <int TM, int TN, bool QUAD, bool GATHER>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int nsplit, int ntap_eff, int tiles_taps) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int nsplit, int ntap_eff, int tiles_taps, int pinned) {
     constexpr int LDA = TM + 4, LDB = TN + 4;  // +4 keeps 16-byte row alignment for the staged float4 writes
     constexpr int WTM = QUAD ? TM / 2 : TM, WTN = QUAD ? TN / 2 : TN;
     constexpr int MB = WTM / 32, NB = WTN / 32;
@@ -40,9 +40,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
     // Workgroup ids go round-robin over the 8 XCDs (one L2 each).  All (tile, tap) workgroups of one
     // K-split read the same 32-pixel chunks of x and dy, so a split is pinned to one XCD: id = 8 j + xcd,
     // split = 8 (j / tiles) + xcd -- its blocks then hit in that XCD's L2 instead of each going to the fabric.
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int split = (jx / tiles_taps) * 8 + xcd;
-    int bid = jx % tiles_taps;
+    int split, bid;
+    if (pinned) {
+        const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+        split = (jx / tiles_taps) * 8 + xcd;
+        bid = jx % tiles_taps;
+    } else {   // a split already has >= 64 workgroups: every XCD gets an eighth of each split
+        split = blockIdx.x / tiles_taps;
+        bid = blockIdx.x - split * tiles_taps;
+    }
     const int tp = bid % ntap_eff; bid /= ntap_eff;   // taps fastest
     const int ct = bid % NTc, nt = bid / NTc;
     const int n0 = nt * TM, c0 = ct * TN;
@@ -234,22 +240,26 @@ int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
     const int ntap = GATHER ? 1 : a.taps.n;
     const int tiles = ((a.N + TM - 1) / TM) * (GATHER ? 1 : a.Cin / TN) * ntap;
     const int total_chunks = (a.M + KP - 1) / KP;
-    // K-splits come in groups of 8 (one per XCD, see the kernel).  Per XCD there are 64 workgroup slots
-    // (32 CUs x 2): pick the group count q whose q * tiles workgroups fill whole rounds of those slots,
-    // with enough chunks per workgroup to amortise its fixed cost (prologue + 64 atomics per lane, about
-    // 2.5 chunks' worth; at least 8 chunks, 16 for 1x1 kernels where all parallelism comes from the split).
+    // How many K-splits.  A workgroup pays a fixed cost (prologue + 64 float atomics per lane, about four
+    // chunks' worth of time, and the atomics are L2 traffic), so prefer few, long splits whose workgroups
+    // fill whole rounds of the resident slots (2 per CU); at least 8 chunks per workgroup, 16 for 1x1
+    // kernels where all the parallelism comes from the split.
+    //  * tiles < 64: splits come in groups of 8, one per XCD (see the kernel): rounds of 64 slots
+    //  * tiles >= 64: a split already fills an XCD; plain order, rounds of all 512 slots
     const int min_chunks = ntap == 1 ? 16 : 8;
-    int qmax = total_chunks / (8 * min_chunks);
+    const int pinned = tiles < 64 ? 1 : 0;
+    const int unit = pinned ? 8 : 1, slots = pinned ? 64 : 512;
+    int qmax = total_chunks / (unit * min_chunks);
     qmax = qmax < 1 ? 1 : (qmax > 64 ? 64 : qmax);
     int best_q = 1;
     double best = -1.0;
     for (int q = 1; q <= qmax; ++q) {
-        const double r = q * tiles / 64.0, rounds = r <= 1.0 ? 1.0 : (double)(long long)(r + 0.999999);
-        const double ch = total_chunks / (8.0 * q);
-        const double score = (r / rounds) * ch / (ch + 2.5);
+        const double r = (double)q * tiles / slots, rounds = r <= 1.0 ? 1.0 : (double)(long long)(r + 0.999999);
+        const double ch = (double)total_chunks / (unit * q);
+        const double score = (r / rounds) * ch / (ch + 4.0);
         if (score > best * 1.005) { best = score; best_q = q; }
     }
-    int nsplit = 8 * best_q;
+    int nsplit = unit * best_q;
     if (nsplit > total_chunks) nsplit = total_chunks;   // tiny problems: empty splits return at once
     static const char* name = QUAD ? "wgrad_kernel<128,128,quad>"
                               : GATHER ? (TM == 64 ? "wgrad_kernel<64,32,gather>" : "wgrad_kernel<32,32,gather>")
@@ -257,8 +267,8 @@ int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
                                          : (TN == 64 ? "wgrad_kernel<32,64>" : "wgrad_kernel<32,32>");
     FvProfScope ps(ctx, name, a.alg_flops,
                    4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.M * a.N + (double)a.N * a.Tw * a.Cin));
-    const int nsplit8 = (nsplit + 7) / 8 * 8;   // padded splits return at once (no chunks)
-    hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER>), dim3(tiles * nsplit8), dim3(256), 0, ctx->stream, a, nsplit, ntap, tiles);
+    const int nsplit8 = pinned ? (nsplit + 7) / 8 * 8 : nsplit;   // padded splits return at once (no chunks)
+    hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER>), dim3(tiles * nsplit8), dim3(256), 0, ctx->stream, a, nsplit, ntap, tiles, pinned);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }
