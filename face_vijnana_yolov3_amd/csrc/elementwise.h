@@ -16,6 +16,9 @@ int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale
 int fv_ew_mse(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int Cpad, float* loss, float* dy, float* dbias);
 int fv_ew_adam(fv_ctx* ctx, float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2, float eps);
 int fv_ew_transpose_ntc(fv_ctx* ctx, const float* src, float* dst, int N, int T, int C, int Npad);
+// the same for up to 64 layers in one launch; offsets in floats from the two base pointers
+int fv_ew_transpose_all(fv_ctx* ctx, const float* src_base, float* dst_base, int nlayers, const long long* src_off,
+                        const long long* dst_off, const int* N, const int* T, const int* C, const int* Npad);
 int fv_ew_pad_rows(fv_ctx* ctx, const float* src, float* dst, int N, int K, int Kpad);
 int fv_ew_slice_cols(fv_ctx* ctx, const float* src, float* dst, long long rows, int C, int Cpad);
 int fv_ew_splitk_finish(fv_ctx* ctx, const float* slabs, int ksplit, long long stride, const float* scale, const float* shift,

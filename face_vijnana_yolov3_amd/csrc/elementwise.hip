@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
         const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
         float4 db = make_float4(0.f, 0.f, 0.f, 0.f), dg = db;
+#pragma unroll 4
         for (long long r = r0 + rl; r < r1; r += rpi) {
             const float4 gv = *reinterpret_cast<const float4*>(g + r * C + c);
             const float4 zv = *reinterpret_cast<const float4*>(z + r * C + c);
@@ -287,6 +288,31 @@ __global__ __launch_bounds__(256) void transpose_ntc_kernel(const float* __restr
     }
 }
 
+// every layer's [N][T][C] -> [C][T][Npad] in one launch: a block finds its layer in the table
+struct TransposeTable { int n; int blk_begin[64]; long long src_off[64]; long long dst_off[64]; int N[64]; int T[64]; int C[64]; int Npad[64]; };
+__global__ __launch_bounds__(256) void transpose_all_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base, TransposeTable tb) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = tb.n - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (tb.blk_begin[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const int N = tb.N[lo], T = tb.T[lo], C = tb.C[lo], Npad = tb.Npad[lo];
+    const float* __restrict__ src = src_base + tb.src_off[lo];
+    float* __restrict__ dst = dst_base + tb.dst_off[lo];
+    int b = blockIdx.x - tb.blk_begin[lo];
+    const int cb = (C + 31) / 32, nb = (Npad + 31) / 32;
+    const int c0 = (b % cb) * 32; b /= cb;
+    const int n0 = (b % nb) * 32; const int t = b / nb;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        int n = n0 + k, c = c0 + tx;
+        tile[k][tx] = (n < N && c < C) ? src[((size_t)n * T + t) * C + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        int c = c0 + k, n = n0 + tx;
+        if (c < C && n < Npad) dst[((size_t)c * T + t) * Npad + n] = tile[tx][k];
+    }
+}
+
 // first-layer kernel [N][K] (K = 27) -> [N][32] zero padded (the gather conv's B operand)
 __global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int K, int Kpad) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -407,6 +433,25 @@ int fv_ew_adam(fv_ctx* ctx, float* p, const float* g, float* m, float* v, long l
 int fv_ew_transpose_ntc(fv_ctx* ctx, const float* src, float* dst, int N, int T, int C, int Npad) {
     FvProfScope ps(ctx, "transpose_ntc_kernel", 0.0, 4.0 * T * C * ((double)N + Npad));
     hipLaunchKernelGGL(transpose_ntc_kernel, dim3((C + 31) / 32, (Npad + 31) / 32, T), dim3(256), 0, ctx->stream, src, dst, N, T, C, Npad);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_ew_transpose_all(fv_ctx* ctx, const float* src_base, float* dst_base, int nlayers, const long long* src_off,
+                        const long long* dst_off, const int* N, const int* T, const int* C, const int* Npad) {
+    FV_REQUIRE(ctx, nlayers >= 1 && nlayers <= 64, "transpose_all: 1..64 layers");
+    TransposeTable tb{};
+    tb.n = nlayers;
+    int blocks = 0;
+    double bytes = 0.0;
+    for (int l = 0; l < nlayers; ++l) {
+        tb.blk_begin[l] = blocks; tb.src_off[l] = src_off[l]; tb.dst_off[l] = dst_off[l];
+        tb.N[l] = N[l]; tb.T[l] = T[l]; tb.C[l] = C[l]; tb.Npad[l] = Npad[l];
+        blocks += ((C[l] + 31) / 32) * ((Npad[l] + 31) / 32) * T[l];
+        bytes += 4.0 * T[l] * C[l] * ((double)N[l] + Npad[l]);
+    }
+    FvProfScope ps(ctx, "transpose_all_kernel", 0.0, bytes);
+    hipLaunchKernelGGL(transpose_all_kernel, dim3(blocks), dim3(256), 0, ctx->stream, src_base, dst_base, tb);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }

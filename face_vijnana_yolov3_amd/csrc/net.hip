@@ -269,9 +269,14 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
     FV_HIP(ctx, hipMemsetAsync(grads, 0, (size_t)N.nparam * sizeof(float), ctx->stream));
     // weight images for this step: packed first layer, transposed kernels for the data-gradients
     if (int rc = fv_ew_pad_rows(ctx, params + N.L[0].w_off, p.w0p, 32, 27, 32)) return rc;
-    for (int l = 1; l < p.nl; ++l) {
-        const auto& d = N.L[l];
-        if (int rc = fv_ew_transpose_ntc(ctx, params + d.w_off, p.wt[l], d.cout, d.ksize * d.ksize, d.cin, d.has_bn ? d.cout : HEAD_PAD)) return rc;
+    {
+        long long so[64], dof[64]; int tn[64], tt[64], tc[64], tp[64];
+        for (int l = 1; l < p.nl; ++l) {
+            const auto& d = N.L[l];
+            so[l - 1] = d.w_off; dof[l - 1] = p.wt[l] - p.wt[1];
+            tn[l - 1] = d.cout; tt[l - 1] = d.ksize * d.ksize; tc[l - 1] = d.cin; tp[l - 1] = d.has_bn ? d.cout : HEAD_PAD;
+        }
+        if (int rc = fv_ew_transpose_all(ctx, params, p.wt[1], p.nl - 1, so, dof, tn, tt, tc, tp)) return rc;
     }
 
     // ---------------- forward (training-mode BN)
