@@ -21,8 +21,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + cl;
     double s = 0.0, q = 0.0;
-    if (c < C)
+    if (c < C) {
+#pragma unroll 8
         for (int r = rl; r < mtiles; r += 128) { s += (double)psum[(size_t)r * C + c]; q += (double)psq[(size_t)r * C + c]; }
+    }
     ssum[rl][cl] = s; ssq[rl][cl] = q;
     __syncthreads();
     for (int st = 64; st > 0; st >>= 1) {   // fixed-order tree: deterministic
@@ -141,8 +143,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + cl;
     double a = 0.0, b = 0.0;
-    if (c < C)
+    if (c < C) {
+#pragma unroll 8
         for (int r = rl; r < chunks; r += 128) { a += (double)pdb[(size_t)r * C + c]; b += (double)pdg[(size_t)r * C + c]; }
+    }
     s1[rl][cl] = a; s2[rl][cl] = b;
     __syncthreads();
     for (int st = 64; st > 0; st >>= 1) {

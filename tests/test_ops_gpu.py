@@ -123,6 +123,7 @@ WGRAD_CASES = [
     (2, 13, 1024, 6, 3, 1, 32),     # head
     (1, 26, 256, 128, 1, 1, 128),
     (4, 26, 128, 256, 3, 1, 256),
+    (2, 16, 256, 512, 3, 1, 512),   # >= 64 (tile, tap) workgroups per K-split: plain split order
 ]
 
 
@@ -138,6 +139,46 @@ def test_conv_wgrad(ctx, B, H, cin, cout, k, s, ndy):
     (bound,) = torch.autograd.grad(_ref_conv(x.double().abs(), wa, k, s), wa, dy[..., :cout].double().abs())
     got = ops.conv2d_wgrad(ctx, x.cuda(), dy.cuda(), cout, k, s)
     _check(got, ref, bound, 'wgrad')
+
+
+def test_conv_tail_split_with_lent_scratch(ctx):
+    """fv_set_conv_scratch: 307 output tiles of 72 K steps -> the launcher cuts every tile into 3 K slices
+    and the fix-up kernel applies the epilogue.  Forward (raw + BN partial sums, fused affine/leaky/add)
+    and stride-1 data-gradient against float64; the unsplit launch differs only in rounding."""
+    from face_vijnana_yolov3_amd import ops
+    B, H, cin, cout = 2, 140, 256, 128
+    x = _rand((B, H, H, cin), 31); w = _rand((cout, 3, 3, cin), 32, -0.1, 0.1)
+    scale = _rand((cout,), 33, 0.5, 1.5); shift = _rand((cout,), 34); skip = _rand((B, H, H, cout), 35)
+    ref = _ref_conv(x.double(), w.double(), 3, 1)
+    bound = _ref_conv(x.double().abs(), w.double().abs(), 3, 1)
+    xd, wd = x.cuda(), w.cuda()
+    plain, _, _ = ops.conv2d_forward(ctx, xd, wd, stride=1, stats=True)
+    ctx.set_conv_scratch(torch.empty(64 << 20, dtype=torch.uint8, device='cuda'))
+    try:
+        out, psum, psq = ops.conv2d_forward(ctx, xd, wd, stride=1, stats=True)
+        out_again, _, _ = ops.conv2d_forward(ctx, xd, wd, stride=1, stats=True)
+        fused = ops.conv2d_forward(ctx, xd, wd, 1, scale.cuda(), shift.cuda(), 0.1, skip.cuda())
+        # data-gradient of a 128 -> 256 conv: the same gather problem with mirrored taps
+        w2 = _rand((cin, 3, 3, cout), 36, -0.1, 0.1); dy = _rand((B, H, H, cin), 37)
+        dgrad = ops.conv2d_dgrad(ctx, dy.cuda(), w2.cuda(), (H, H), 1)
+    finally:
+        ctx.set_conv_scratch(None)
+    dgrad_plain = ops.conv2d_dgrad(ctx, dy.cuda(), w2.cuda(), (H, H), 1)
+    assert torch.equal(out, out_again)                      # deterministic
+    assert not torch.equal(out, plain)                      # the split really ran (other summation order)
+    _check(out, ref, bound, 'tail-split fwd')
+    _check(plain, ref, bound, 'unsplit fwd')
+    rows = ref.numel() // cout
+    _check(psum.sum(0), ref.view(rows, cout).sum(0), bound.view(rows, cout).sum(0), 'psum')
+    _check(psq.sum(0), (ref.view(rows, cout) ** 2).sum(0), (bound.view(rows, cout) ** 2).sum(0) * 2, 'psq')
+    ref_f = F.leaky_relu(ref * scale.double() + shift.double(), 0.1) + skip.double()
+    _check(fused, ref_f, bound * scale.double().abs() + 2.0, 'tail-split fused epilogue')
+    xg = torch.zeros((B, H, H, cout), dtype=torch.float64, requires_grad=True)
+    (ref_d,) = torch.autograd.grad(_ref_conv(xg, w2.double(), 3, 1), xg, dy.double())
+    xa = torch.zeros((B, H, H, cout), dtype=torch.float64, requires_grad=True)
+    (bound_d,) = torch.autograd.grad(_ref_conv(xa, w2.double().abs(), 3, 1), xa, dy.double().abs())
+    _check(dgrad, ref_d, bound_d, 'tail-split dgrad')
+    assert not torch.equal(dgrad, dgrad_plain)
 
 
 @pytest.mark.parametrize('rows,C', [(1000, 32), (4097, 64), (338, 1024), (70000, 128)])
