@@ -181,6 +181,36 @@ def test_conv_tail_split_with_lent_scratch(ctx):
     assert not torch.equal(dgrad, dgrad_plain)
 
 
+@pytest.mark.parametrize('B,H,cin,cout,k', [(4, 3, 512, 1024, 3), (4, 6, 512, 256, 1), (2, 13, 1024, 6, 3), (3, 8, 64, 128, 3),
+                                            (2, 140, 256, 128, 3)])
+def test_k_split_slabs_are_reused_safely(ctx, B, H, cin, cout, k):
+    """Two different problems of one shape alternate through the SAME lent scratch: each result must be
+    bit-identical every time (a slab line left over from the previous launch -- per-XCD L2s are not
+    coherent -- would show up here) and within rounding of the launch without scratch.  The last shape
+    takes the tail split (307 tiles); the small ones document that lending scratch is harmless there."""
+    from face_vijnana_yolov3_amd import ops
+    xs = [_rand((B, H, H, cin), 40 + i).cuda() for i in range(2)]
+    ws = [_rand((cout, k, k, cin), 50 + i, -0.1, 0.1).cuda() for i in range(2)]
+    sc = _rand((cout,), 60, 0.5, 1.5).cuda(); sh = _rand((cout,), 61).cuda()
+    skip = _rand((B, H, H, cout), 62).cuda()
+    plain = [ops.conv2d_forward(ctx, xs[i], ws[i], 1, sc, sh, 0.1, skip) for i in range(2)]
+    ctx.set_conv_scratch(torch.empty(96 << 20, dtype=torch.uint8, device='cuda'))
+    try:
+        first = [None, None]
+        for rep in range(6):
+            i = rep & 1
+            out = ops.conv2d_forward(ctx, xs[i], ws[i], 1, sc, sh, 0.1, skip)
+            if first[i] is None:
+                first[i] = out
+            else:
+                assert torch.equal(out, first[i]), (rep, (out - first[i]).abs().max().item())
+    finally:
+        ctx.set_conv_scratch(None)
+    for i in range(2):
+        d = (first[i] - plain[i]).abs().max().item()
+        assert d <= 2e-5 * plain[i].abs().max().item(), d
+
+
 @pytest.mark.parametrize('rows,C', [(1000, 32), (4097, 64), (338, 1024), (70000, 128)])
 def test_bn_forward_backward(ctx, rows, C):
     from face_vijnana_yolov3_amd import ops
