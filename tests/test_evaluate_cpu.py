@@ -1,0 +1,66 @@
+"""cal_mAP_fd (reference evaluate.py:27-127): the product's vectorised restatement against the
+loop-level oracle and a hand-computed case.  Parity unpinned against the reference itself (its
+function raises under every pandas release, see face_vijnana_yolov3_amd/evaluate.py)."""
+import os
+
+import numpy as np
+import pytest
+
+
+def _write(tmp_path, gt_rows, sol_rows):
+    gt = os.path.join(tmp_path, 'validation.csv'); sol = os.path.join(tmp_path, 'solution_fd.csv')
+    with open(gt, 'w') as f:
+        f.write('FACE_ID,FILE,SUBJECT_ID,FACE_X,FACE_Y,FACE_WIDTH,FACE_HEIGHT\n')
+        for k, r in enumerate(gt_rows):
+            f.write('%d,%s,%d,%s,%s,%s,%s\n' % (k, r[0], 1, r[1], r[2], r[3], r[4]))
+    with open(sol, 'w') as f:
+        for r in sol_rows:
+            f.write('%s,%s,%s,%s,%s,%s\n' % tuple(r))
+    return gt, sol
+
+
+def test_hand_computed_case(tmp_path):
+    from face_vijnana_yolov3_amd.evaluate import cal_mAP_fd
+    # image a: two faces, three detections (one exact, one half-overlapping, one far away);
+    # image b: one face, no detection at all; image c: detection that overlaps nothing -> dropped
+    gt_rows = [('a.jpg', 10, 10, 20, 20), ('a.jpg', 100, 100, 40, 40), ('b.jpg', 5, 5, 10, 10), ('c.jpg', 0, 0, 10, 10)]
+    sol_rows = [('a.jpg', 10, 10, 20, 20, 0.9),      # IoU 1 with gt 0
+                ('a.jpg', 120, 100, 40, 40, 0.8),    # IoU (20*40)/(2*1600-800) = 1/3 with gt 1
+                ('a.jpg', 300, 300, 10, 10, 0.7),    # no overlap -> -1
+                ('c.jpg', 50, 50, 5, 5, 0.95)]       # image c has no overlapping pair -> not counted
+    gt, sol = _write(str(tmp_path), gt_rows, sol_rows)
+    ps, rs, m = cal_mAP_fd(gt, sol, 0.5)
+    assert np.allclose(ps, [1.0, 0.5, 1 / 3]) and np.allclose(rs, [0.25, 0.25, 0.25]) and m == 0.0
+    ps, rs, m = cal_mAP_fd(gt, sol, 0.3)
+    assert np.allclose(ps, [1.0, 1.0, 2 / 3]) and np.allclose(rs, [0.25, 0.5, 0.5])
+    assert abs(m - 0.25) < 1e-9           # precision 1 over recall 0.25 .. 0.5
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_matches_loop_oracle(tmp_path, seed):
+    from face_vijnana_yolov3_amd.evaluate import cal_mAP_fd, cal_mAP_sweep
+    from oracle import evaluate_oracle as eo
+    rng = np.random.default_rng(seed)
+    gt_rows, sol_rows = [], []
+    for k in range(40):
+        name = 'img_%03d.jpg' % k
+        n = int(rng.integers(1, 6))
+        for _ in range(n):
+            x, y = rng.uniform(1, 800, 2); w, h = rng.uniform(20, 120, 2)
+            gt_rows.append((name, round(x, 1), round(y, 1), round(w, 1), round(h, 1)))
+            if rng.random() < 0.8:      # a jittered detection of this face
+                j = rng.normal(0, 12, 4)
+                sol_rows.append((name, x + j[0], y + j[1], max(w + j[2], 4), max(h + j[3], 4), rng.uniform(0.3, 1.0)))
+        for _ in range(int(rng.integers(0, 4))):   # false positives
+            sol_rows.append((name, rng.uniform(1, 900), rng.uniform(1, 900), rng.uniform(10, 80), rng.uniform(10, 80), rng.uniform(0.1, 0.9)))
+    sol_rows.append(('not_in_gt.jpg', 1, 1, 10, 10, 0.99))
+    gt, sol = _write(str(tmp_path), gt_rows, sol_rows)
+    for th in (0.5, 0.65, 0.8):
+        ps, rs, m = cal_mAP_fd(gt, sol, th)
+        ops_, ors, om = eo.cal_mAP_fd(gt, sol, th)
+        assert np.array_equal(ps, np.asarray(ops_)) and np.array_equal(rs, np.asarray(ors))
+        assert m == om
+    res, mean = cal_mAP_sweep(gt, sol)
+    assert len(res) == 10 and abs(res[0][0] - 0.5) < 1e-12 and abs(res[-1][0] - 0.95) < 1e-9
+    assert all(res[i][1] >= res[i + 1][1] - 1e-12 for i in range(9))       # AP falls as the IoU bar rises
+    assert abs(mean - np.mean([m for _, m in res])) < 1e-15
