@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
     // balanced partition of the chunks over the splits (sizes differ by at most one)
     const int ch_begin = (int)((long long)split * total_chunks / nsplit);
     const int ch_end = (int)((long long)(split + 1) * total_chunks / nsplit);
-    if (ch_begin >= ch_end) return;
+    if (split >= nsplit || ch_begin >= ch_end) return;   // padded split ids (pinned mode) own no chunks
 
     f32x16 acc[MB][NB];
 #pragma unroll
