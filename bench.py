@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 IMAGE_SIZE = 416
 PER_GPU_BATCH = 40
 FP32_MFMA_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s is what a float4 copy reaches)
 DOMINANT = 'conv_kernel<128,2,2,false>'
 HPS = dict(lr=1e-4, beta_1=0.99, beta_2=0.99, decay=0.0)  # reference face_vijnana_yolov3.json:12-15
 
@@ -222,6 +223,11 @@ def main():
             'roofline': roofline,
             'roofline_overlapped': (lambda d: None if not d or not d['ms'] else dict(
                 achieved=round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2), avg_launch_ms=round(d['ms'] / d['launches'], 4)))(prof_ov.get(DOMINANT)),
+            # the HBM-bound companions (algorithmic bytes / HIP-event time, against the 8 TB/s HBM3E peak)
+            'roofline_hbm': {k: dict(bound='hbm', achieved=v['gbps'], peak=HBM_PEAK_GBPS, unit='GB/s',
+                                     frac=round(v['gbps'] / HBM_PEAK_GBPS, 4), ms_per_step=v['ms_per_step'])
+                             for k, v in kernels.items()
+                             if k in ('bn_act_kernel', 'bn_bwd_apply_kernel', 'bn_bwd_reduce_kernel', 'adam_kernel') and v['gbps']},
             'detect': detect,
             'kernels': kernels,
         }
