@@ -79,8 +79,13 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float4* __restrict__ 
                                                      const float* __restrict__ shift, const float4* __restrict__ skip,
                                                      float4* __restrict__ out, long long n4, int C, float leaky) {
     const int c4n = C >> 2;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4n) << 2;
+    // channel group of element i, advanced incrementally (one 64-bit modulo per thread, not per element)
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int cstep = (int)(stride % c4n);
+    long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    int cg = (int)(i % c4n);
+    for (; i < n4; i += stride, cg += cstep, cg -= cg >= c4n ? c4n : 0) {
+        const int c = cg << 2;
         float4 v = z[i];
         const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
@@ -163,8 +168,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
                                                            const float* __restrict__ dbeta, const float* __restrict__ dgamma,
                                                            float inv_count, long long n4, int C, float leaky, float4* __restrict__ dz) {
     const int c4n = C >> 2;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4n) << 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int cstep = (int)(stride % c4n);
+    long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    int cg = (int)(i % c4n);
+    for (; i < n4; i += stride, cg += cstep, cg -= cg >= c4n ? c4n : 0) {
+        const int c = cg << 2;
         const float4 gv = g[i], zv = z[i];
         const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
         const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
@@ -375,7 +384,7 @@ int fv_ew_bn_act(fv_ctx* ctx, const float* z, const float* scale, const float* s
     FV_REQUIRE(ctx, C % 4 == 0, "bn_act: C must be a multiple of 4");
     long long n4 = rows * C / 4;
     FvProfScope ps(ctx, "bn_act_kernel", 0.0, 4.0 * rows * C * (skip ? 3 : 2));
-    hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, ctx->stream, (const float4*)z, scale, shift,
+    hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(n4, 256, 256 * 16)), dim3(256), 0, ctx->stream, (const float4*)z, scale, shift,
                        (const float4*)skip, (float4*)out, n4, C, leaky);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
@@ -405,7 +414,7 @@ int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale
     FV_LAUNCH_CHECK(ctx);
     long long n4 = rows * C / 4;
     FvProfScope ps(ctx, "bn_bwd_apply_kernel", 0.0, 12.0 * rows * C);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, ctx->stream, (const float4*)g, (const float4*)z,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4, 256, 256 * 16)), dim3(256), 0, ctx->stream, (const float4*)g, (const float4*)z,
                        scale, shift, mean, invstd, dbeta, dgamma, (float)(1.0 / (double)rows), n4, C, leaky, (float4*)dz);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
