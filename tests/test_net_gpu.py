@@ -258,3 +258,18 @@ def test_config5_608_grid19(eng):
     torch.cuda.synchronize()
     assert abs(loss.item() - l64.item()) <= 4 * abs(l32.item() - l64.item()) + 1e-6 * abs(l64.item())
     _grad_close(eng.grads.cpu(), g64, g32, 'gradient 608')
+
+
+def test_overfits_one_fixed_batch(eng):
+    """End-to-end sanity beyond oracle parity: forward, backward and the Keras-formula Adam together
+    drive the MSE of one fixed synthetic batch down by more than an order of magnitude."""
+    from face_vijnana_yolov3_amd import data
+    B, S = 4, 128
+    eng.init_synthetic(seed=7)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand((B, S, S, 3), generator=g).cuda()
+    y = torch.from_numpy(data.synth_gt_batch(B, S, seed=5)).cuda()
+    losses = [eng.train_on_batch(x, y, 1e-4, 0.99, 0.99).item() for _ in range(80)]
+    assert all(np.isfinite(losses)) and bool(torch.isfinite(eng.params).all())
+    assert losses[-1] < 0.05 * losses[0], (losses[0], losses[-1])
+    assert min(losses[40:]) < min(losses[:20])
