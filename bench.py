@@ -227,7 +227,7 @@ def main():
             'roofline_hbm': {k: dict(bound='hbm', achieved=v['gbps'], peak=HBM_PEAK_GBPS, unit='GB/s',
                                      frac=round(v['gbps'] / HBM_PEAK_GBPS, 4), ms_per_step=v['ms_per_step'])
                              for k, v in kernels.items()
-                             if k in ('bn_act_kernel', 'bn_bwd_apply_kernel', 'bn_bwd_reduce_kernel', 'adam_kernel') and v['gbps']},
+                             if k in ('bn_act_stats_kernel', 'bn_bwd_apply_slots_kernel', 'bn_bwd_reduce_kernel', 'adam_kernel') and v['gbps']},
             'detect': detect,
             'kernels': kernels,
         }

@@ -26,6 +26,8 @@ struct FvConvArgs {
     const float* shift;   // FV_EPI_AFFINE: per-n (may be NULL = 0)
     float* psum;          // FV_EPI_STATS: [mtiles][Nout] per-tile column sums of the raw result
     float* psq;           //                and of its squares
+    double* stat_slots;   // FV_EPI_STATS, alternative to psum/psq: [stat_nslot][2][Nout] accumulators (sum, sum of
+    int stat_nslot;       //   squares); tile mt ADDS its column sums to slot mt % stat_nslot (fp64 atomics)
     int B, Hin, Win, Cin;
     int Hl, Wl;
     int Hout, Wout, Nout;

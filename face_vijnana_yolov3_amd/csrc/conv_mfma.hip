@@ -32,6 +32,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + pos;
 }
 
+// Column sum / sum of squares of one tile: either its own partial row (deterministic; reduced later by
+// bn_finalize) or added to one of a few fp64 accumulator slots (fp32 partials are exact in fp64; only
+// the order of the fp64 additions varies, far below fp32 resolution) which the consumer kernel sums
+// itself -- that saves the finalize launch between the conv and the normalise pass.
+__device__ __forceinline__ void stat_store(const FvConvArgs& a, int mt, int n, float s, float q) {
+    if (a.stat_slots) {
+        double* sl = a.stat_slots + (size_t)(mt % a.stat_nslot) * 2 * a.Nout;
+        unsafeAtomicAdd(sl + n, (double)s);
+        unsafeAtomicAdd(sl + a.Nout + n, (double)q);
+    } else {
+        a.psum[(size_t)mt * a.Nout + n] = s;
+        a.psq[(size_t)mt * a.Nout + n] = q;
+    }
+}
+
 template <int BN, int WAVES_M, int WAVES_N, bool GATHER>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -315,8 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < WAVES_M; ++w) { s += red[0][w][tid]; q += red[1][w][tid]; }
-            a.psum[(size_t)mt * a.Nout + n0 + tid] = s;
-            a.psq[(size_t)mt * a.Nout + n0 + tid] = q;
+            stat_store(a, mt, n0 + tid, s, q);
         }
     }
     if ((a.Nout & 3) == 0) {
@@ -453,8 +467,7 @@ __global__ __launch_bounds__(1024) void conv_tail_fixup_kernel(const FvConvArgs 
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < RL; ++w) { s += red[0][w][tid]; q += red[1][w][tid]; }
-            a.psum[(size_t)mt * a.Nout + n0 + tid] = s;
-            a.psq[(size_t)mt * a.Nout + n0 + tid] = q;
+            stat_store(a, mt, n0 + tid, s, q);
         }
     }
 }
@@ -628,8 +641,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel_dma(const FvConvArgs a) {
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < WAVES_M; ++w) { s += red[0][w][tid]; q += red[1][w][tid]; }
-            a.psum[(size_t)mt * a.Nout + n0 + tid] = s;
-            a.psq[(size_t)mt * a.Nout + n0 + tid] = q;
+            stat_store(a, mt, n0 + tid, s, q);
         }
     }
 #pragma unroll
@@ -746,7 +758,8 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
                         (long long)a.B * a.Hout * a.Wout * a.Nout < (1ll << 31) &&
                         (long long)a.Nout * a.Tw * a.Cin < (1ll << 29),
                "conv: input/weight tensor exceeds 2^29 elements (2 GiB buffer descriptor) or output 2^31");
-    FV_REQUIRE(ctx, !(a.epi & FV_EPI_STATS) || (a.psum && a.psq && a.nclass == 1), "conv: stats need psum/psq");
+    FV_REQUIRE(ctx, !(a.epi & FV_EPI_STATS) || (((a.psum && a.psq) || (a.stat_slots && a.stat_nslot >= 1)) && a.nclass == 1),
+               "conv: stats need psum/psq or accumulator slots");
     FV_REQUIRE(ctx, !(a.epi & FV_EPI_ADD) || a.addend, "conv: FV_EPI_ADD needs addend");
     FV_REQUIRE(ctx, a.ksplit <= 1 || (a.epi == 0 && a.nclass == 1 && a.Cin % BK == 0), "conv: split-K stores raw partials only");
     const bool gather = a.Cin % BK != 0;

@@ -12,9 +12,16 @@ int fv_ew_bn_act(fv_ctx* ctx, const float* z, const float* scale, const float* s
 int fv_ew_bn_bwd_chunks(long long rows, int C);
 int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale, const float* shift, const float* mean,
                  const float* invstd, long long rows, int C, float leaky, float* pdb, float* pdg, float* dbeta, float* dgamma,
-                 float* dz);
+                 float* dz, double* slots = nullptr, int nslot = 0);
 int fv_ew_mse(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int Cpad, float* loss, float* dy, float* dbias);
 int fv_ew_adam(fv_ctx* ctx, float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2, float eps);
+// training-mode BN without a finalize launch: the conv epilogue adds its column sums to
+// [nslot][2][C] fp64 accumulator slots (zeroed by the caller); this pass sums them, normalises, and
+// publishes mean/invstd/scale/shift (+ moving statistics) for the backward pass
+int fv_ew_bn_stat_slots(int C);
+int fv_ew_bn_act_stats(fv_ctx* ctx, const float* z, const double* slots, int nslot, double count, const float* gamma,
+                       const float* beta, float eps, float momentum, float* mean, float* invstd, float* scale, float* shift,
+                       float* moving_mean, float* moving_var, const float* skip, float* out, long long rows, int C, float leaky);
 int fv_ew_transpose_ntc(fv_ctx* ctx, const float* src, float* dst, int N, int T, int C, int Npad);
 // the same for up to 64 layers in one launch; offsets in floats from the two base pointers
 int fv_ew_transpose_all(fv_ctx* ctx, const float* src_base, float* dst_base, int nlayers, const long long* src_off,

@@ -96,13 +96,82 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float4* __restrict__ 
     }
 }
 
+// The same pass fed by the conv epilogue's accumulator slots (conv.h stat_slots): every workgroup first
+// turns the slots into scale/shift for all C channels (fixed summation order over the slots, fp64,
+// 16 loads per thread) and keeps them in LDS; workgroup 0 also publishes mean / invstd / scale / shift
+// for the backward pass and updates the moving statistics -- no finalize launch in between.
+__global__ __launch_bounds__(256) void bn_act_stats_kernel(const float4* __restrict__ z, const double* __restrict__ slots, int nslot,
+                                                           double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, float momentum, float* __restrict__ mean_out,
+                                                           float* __restrict__ invstd_out, float* __restrict__ scale_out,
+                                                           float* __restrict__ shift_out, float* __restrict__ moving_mean,
+                                                           float* __restrict__ moving_var, const float4* __restrict__ skip,
+                                                           float4* __restrict__ out, long long n4, int C, float leaky) {
+    __shared__ __attribute__((aligned(16))) float s_sc[1024], s_sh[1024];
+    __shared__ double s_part[2][256];
+    const int tid = threadIdx.x;
+    auto finish = [&](int c, double s, double q) {
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd, sh = beta[c] - (float)mean * sc;
+        s_sc[c] = sc; s_sh[c] = sh;
+        if (blockIdx.x == 0) {
+            mean_out[c] = (float)mean; invstd_out[c] = invstd; scale_out[c] = sc; shift_out[c] = sh;
+            if (moving_mean) {   // Keras 2.2.4 BatchNormalization: EMA of batch mean and of var * n/(n-(1+eps))
+                const double corr = count / (count - (1.0 + (double)eps));
+                moving_mean[c] = momentum * moving_mean[c] + (1.0f - momentum) * (float)mean;
+                moving_var[c] = momentum * moving_var[c] + (1.0f - momentum) * (float)(var * corr);
+            }
+        }
+    };
+    if (C >= 256) {
+        for (int c = tid; c < C; c += 256) {
+            double s = 0.0, q = 0.0;
+            for (int k = 0; k < nslot; ++k) { s += slots[(size_t)(2 * k) * C + c]; q += slots[(size_t)(2 * k + 1) * C + c]; }
+            finish(c, s, q);
+        }
+    } else {
+        // C < 256 (a power of two >= 32 here): 256 / C thread groups share the slots of a channel
+        const int G = 256 / C, g = tid / C, c = tid % C;
+        double s = 0.0, q = 0.0;
+        if (g < G)
+            for (int k = g; k < nslot; k += G) { s += slots[(size_t)(2 * k) * C + c]; q += slots[(size_t)(2 * k + 1) * C + c]; }
+        s_part[0][tid] = s; s_part[1][tid] = q;
+        __syncthreads();
+        if (tid < C) {
+            s = 0.0; q = 0.0;
+            for (int j = 0; j < G; ++j) { s += s_part[0][j * C + tid]; q += s_part[1][j * C + tid]; }
+            finish(tid, s, q);
+        }
+    }
+    __syncthreads();
+    const int c4n = C >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int cstep = (int)(stride % c4n);
+    long long i = blockIdx.x * (long long)blockDim.x + tid;
+    int cg = (int)(i % c4n);
+    for (; i < n4; i += stride, cg += cstep, cg -= cg >= c4n ? c4n : 0) {
+        const int c = cg << 2;
+        float4 v = z[i];
+        const float4 sc = *reinterpret_cast<const float4*>(s_sc + c), sh = *reinterpret_cast<const float4*>(s_sh + c);
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        v.x = v.x > 0.f ? v.x : v.x * leaky; v.y = v.y > 0.f ? v.y : v.y * leaky;
+        v.z = v.z > 0.f ? v.z : v.z * leaky; v.w = v.w > 0.f ? v.w : v.w * leaky;
+        if (skip) { float4 sk = skip[i]; v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w; }
+        out[i] = v;
+    }
+}
+
 // ---------------------------------------------------------------- BN + leaky backward
 // pass 1: per-channel partial sums of gy and gy*xhat over a chunk of rows; gy = g * leaky'(y)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ z,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             long long M, int C, int rows_per_block, float leaky,
-                                                            float* __restrict__ pdb, float* __restrict__ pdg) {
+                                                            float* __restrict__ pdb, float* __restrict__ pdg,
+                                                            double* __restrict__ slots, int nslot) {
     // thread layout: tpr = min(C/4, 256) threads per row, 256/tpr rows in flight
     __shared__ float4 sdb[256], sdg[256];
     const int c4n = C >> 2;
@@ -134,8 +203,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 db.x += b.x; db.y += b.y; db.z += b.z; db.w += b.w;
                 dg.x += d.x; dg.y += d.y; dg.z += d.z; dg.w += d.w;
             }
-            *reinterpret_cast<float4*>(pdb + (size_t)blockIdx.x * C + c) = db;
-            *reinterpret_cast<float4*>(pdg + (size_t)blockIdx.x * C + c) = dg;
+            if (slots) {   // [nslot][2][C] fp64 accumulators; the apply pass sums them itself (no finalize launch)
+                double* sl = slots + (size_t)(blockIdx.x % nslot) * 2 * C + c;
+                unsafeAtomicAdd(sl + 0, (double)db.x); unsafeAtomicAdd(sl + 1, (double)db.y);
+                unsafeAtomicAdd(sl + 2, (double)db.z); unsafeAtomicAdd(sl + 3, (double)db.w);
+                unsafeAtomicAdd(sl + C + 0, (double)dg.x); unsafeAtomicAdd(sl + C + 1, (double)dg.y);
+                unsafeAtomicAdd(sl + C + 2, (double)dg.z); unsafeAtomicAdd(sl + C + 3, (double)dg.w);
+            } else {
+                *reinterpret_cast<float4*>(pdb + (size_t)blockIdx.x * C + c) = db;
+                *reinterpret_cast<float4*>(pdg + (size_t)blockIdx.x * C + c) = dg;
+            }
         }
         __syncthreads();
     }
@@ -178,6 +255,61 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
         const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
         const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
         const float4 db = *reinterpret_cast<const float4*>(dbeta + c), dg = *reinterpret_cast<const float4*>(dgamma + c);
+        float4 o;
+        float gy;
+        gy = (zv.x * sc.x + sh.x) > 0.f ? gv.x : gv.x * leaky; o.x = sc.x * (gy - db.x * inv_count - (zv.x - mu.x) * is.x * (dg.x * inv_count));
+        gy = (zv.y * sc.y + sh.y) > 0.f ? gv.y : gv.y * leaky; o.y = sc.y * (gy - db.y * inv_count - (zv.y - mu.y) * is.y * (dg.y * inv_count));
+        gy = (zv.z * sc.z + sh.z) > 0.f ? gv.z : gv.z * leaky; o.z = sc.z * (gy - db.z * inv_count - (zv.z - mu.z) * is.z * (dg.z * inv_count));
+        gy = (zv.w * sc.w + sh.w) > 0.f ? gv.w : gv.w * leaky; o.w = sc.w * (gy - db.w * inv_count - (zv.w - mu.w) * is.w * (dg.w * inv_count));
+        dz[i] = o;
+    }
+}
+
+// pass 2 fed by accumulator slots: every workgroup sums the slots of all channels first (as
+// bn_act_stats_kernel does); workgroup 0 writes d-beta / d-gamma into the gradient vector
+__global__ __launch_bounds__(256) void bn_bwd_apply_slots_kernel(const float4* __restrict__ g, const float4* __restrict__ z,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const double* __restrict__ slots, int nslot,
+                                                                 float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                                 float inv_count, long long n4, int C, float leaky, float4* __restrict__ dz) {
+    __shared__ __attribute__((aligned(16))) float s_db[1024], s_dg[1024];
+    __shared__ double s_part[2][256];
+    const int tid = threadIdx.x;
+    auto finish = [&](int c, double a, double b) {
+        s_db[c] = (float)a; s_dg[c] = (float)b;
+        if (blockIdx.x == 0) { dbeta[c] = (float)a; dgamma[c] = (float)b; }
+    };
+    if (C >= 256) {
+        for (int c = tid; c < C; c += 256) {
+            double a = 0.0, b = 0.0;
+            for (int k = 0; k < nslot; ++k) { a += slots[(size_t)(2 * k) * C + c]; b += slots[(size_t)(2 * k + 1) * C + c]; }
+            finish(c, a, b);
+        }
+    } else {
+        const int G = 256 / C, gi = tid / C, c = tid % C;
+        double a = 0.0, b = 0.0;
+        for (int k = gi; k < nslot; k += G) { a += slots[(size_t)(2 * k) * C + c]; b += slots[(size_t)(2 * k + 1) * C + c]; }
+        s_part[0][tid] = a; s_part[1][tid] = b;
+        __syncthreads();
+        if (tid < C) {
+            a = 0.0; b = 0.0;
+            for (int j = 0; j < G; ++j) { a += s_part[0][j * C + tid]; b += s_part[1][j * C + tid]; }
+            finish(tid, a, b);
+        }
+    }
+    __syncthreads();
+    const int c4n = C >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int cstep = (int)(stride % c4n);
+    long long i = blockIdx.x * (long long)blockDim.x + tid;
+    int cg = (int)(i % c4n);
+    for (; i < n4; i += stride, cg += cstep, cg -= cg >= c4n ? c4n : 0) {
+        const int c = cg << 2;
+        const float4 gv = g[i], zv = z[i];
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+        const float4 db = *reinterpret_cast<const float4*>(s_db + c), dg = *reinterpret_cast<const float4*>(s_dg + c);
         float4 o;
         float gy;
         gy = (zv.x * sc.x + sh.x) > 0.f ? gv.x : gv.x * leaky; o.x = sc.x * (gy - db.x * inv_count - (zv.x - mu.x) * is.x * (dg.x * inv_count));
@@ -390,6 +522,28 @@ int fv_ew_bn_act(fv_ctx* ctx, const float* z, const float* scale, const float* s
     return FV_OK;
 }
 
+int fv_ew_bn_stat_slots(int C) {
+    // slots x channels = 2048 accumulator pairs (16 fp64 loads per thread in the consumer's prologue)
+    int n = 2048 / (C < 1 ? 1 : C);
+    return n < 2 ? 2 : (n > 64 ? 64 : n);
+}
+
+int fv_ew_bn_act_stats(fv_ctx* ctx, const float* z, const double* slots, int nslot, double count, const float* gamma,
+                       const float* beta, float eps, float momentum, float* mean, float* invstd, float* scale, float* shift,
+                       float* moving_mean, float* moving_var, const float* skip, float* out, long long rows, int C, float leaky) {
+    FV_REQUIRE(ctx, C % 4 == 0 && C <= 1024 && (C >= 256 || 256 % C == 0), "bn_act_stats: C must be a multiple of 4, <= 1024, and divide 256 when below it");
+    FV_REQUIRE(ctx, nslot >= 1 && slots, "bn_act_stats: no accumulator slots");
+    long long n4 = rows * C / 4;
+    FvProfScope ps(ctx, "bn_act_stats_kernel", 0.0, 4.0 * rows * C * (skip ? 3 : 2));
+    // 4 workgroups per CU: the slot reduction in front of the stream is paid once per workgroup (measured:
+    // 4096 / 2048 / 1024 / 512 workgroups -> 2.78 / 2.57 / 2.47 / 3.03 ms per step over the 52 layers)
+    hipLaunchKernelGGL(bn_act_stats_kernel, dim3(grid_for(n4, 256, 256 * 4)), dim3(256), 0, ctx->stream, (const float4*)z, slots, nslot,
+                       count, gamma, beta, eps, momentum, mean, invstd, scale, shift, moving_mean, moving_var, (const float4*)skip,
+                       (float4*)out, n4, C, leaky);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
 int fv_ew_bn_bwd_chunks(long long rows, int C) {
     // ~2048 blocks, at least 64 rows each
     long long rpb = (rows + 2047) / 2048;
@@ -399,17 +553,27 @@ int fv_ew_bn_bwd_chunks(long long rows, int C) {
 
 int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale, const float* shift, const float* mean,
                  const float* invstd, long long rows, int C, float leaky, float* pdb, float* pdg, float* dbeta, float* dgamma,
-                 float* dz) {
+                 float* dz, double* slots, int nslot) {
     FV_REQUIRE(ctx, C % 4 == 0, "bn_bwd: C must be a multiple of 4");
+    FV_REQUIRE(ctx, !slots || (nslot >= 1 && C <= 1024 && (C >= 256 || 256 % C == 0)), "bn_bwd: accumulator slots need C <= 1024 dividing or divided by 256");
     long long rpb = (rows + 2047) / 2048;
     if (rpb < 64) rpb = 64;
     int chunks = (int)((rows + rpb - 1) / rpb);
     {
         FvProfScope ps(ctx, "bn_bwd_reduce_kernel", 0.0, 8.0 * rows * C);
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(chunks), dim3(256), 0, ctx->stream, g, z, scale, shift, mean, invstd, rows, C,
-                           (int)rpb, leaky, pdb, pdg);
+                           (int)rpb, leaky, pdb, pdg, slots, nslot);
     }
     FV_LAUNCH_CHECK(ctx);
+    if (slots) {
+        long long n4s = rows * C / 4;
+        FvProfScope ps(ctx, "bn_bwd_apply_slots_kernel", 0.0, 12.0 * rows * C);
+        hipLaunchKernelGGL(bn_bwd_apply_slots_kernel, dim3(grid_for(n4s, 256, 256 * 4)), dim3(256), 0, ctx->stream, (const float4*)g,
+                           (const float4*)z, scale, shift, mean, invstd, slots, nslot, dbeta, dgamma, (float)(1.0 / (double)rows), n4s, C,
+                           leaky, (float4*)dz);
+        FV_LAUNCH_CHECK(ctx);
+        return FV_OK;
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, ctx->stream, pdb, pdg, chunks, C, dbeta, dgamma);
     FV_LAUNCH_CHECK(ctx);
     long long n4 = rows * C / 4;

@@ -69,7 +69,10 @@ struct Carver {
 struct Plan {
     int B, S, nl;
     std::vector<float*> z, a, mean, invstd, scale, shift, wt;
-    float *psum, *psq, *pdb, *pdg, *w0p, *yhat, *dyp, *G[3], *D[2], *loss, *slab, *tail;
+    std::vector<double*> slots, bslots;   // per layer [nslot][2][cout] fp64 accumulators, forward statistics and
+                                          // backward d-beta/d-gamma (one contiguous range over all layers)
+    size_t slots_bytes;
+    float *w0p, *yhat, *dyp, *G[3], *D[2], *loss, *slab, *tail;
     size_t tail_floats;
     size_t bytes;
 };
@@ -94,16 +97,13 @@ Plan make_plan(void* base, int B, int S, bool training) {
     const int nb = p.nl - 1;
     p.z.resize(nb); p.a.resize(nb); p.mean.resize(nb); p.invstd.resize(nb); p.scale.resize(nb); p.shift.resize(nb);
     p.wt.resize(p.nl);
-    size_t max_act = 0, max_part = 0, max_bwd = 0;
+    p.slots.resize(nb); p.bslots.resize(nb);
+    size_t max_act = 0;
     for (int l = 0; l < nb; ++l) {
         const auto& d = N.L[l];
         size_t hw = (size_t)(S / d.out_div) * (S / d.out_div);
         size_t rows = (size_t)B * hw, elems = rows * d.cout;
         if (elems > max_act) max_act = elems;
-        size_t part = (size_t)fv_conv_mtiles((int)rows, d.cout) * d.cout;
-        if (part > max_part) max_part = part;
-        size_t bw = (size_t)fv_ew_bn_bwd_chunks((long long)rows, d.cout) * d.cout;
-        if (bw > max_bwd) max_bwd = bw;
     }
     {   // per-channel BN vectors of all layers are contiguous (channel offset = mean_off / 2)
         float* sc_all = c.take((size_t)N.nstate / 2);
@@ -129,8 +129,18 @@ Plan make_plan(void* base, int B, int S, bool training) {
             int cp = d.has_bn ? d.cout : HEAD_PAD;
             p.wt[l] = c.take((size_t)d.cin * d.ksize * d.ksize * cp);
         }
-        p.psum = c.take(max_part); p.psq = c.take(max_part);
-        p.pdb = c.take(max_bwd); p.pdg = c.take(max_bwd);
+        {   // accumulator slots of all layers in one range (zeroed by one memset per step)
+            size_t tot = 0;
+            for (int l = 0; l < nb; ++l) tot += (size_t)fv_ew_bn_stat_slots(N.L[l].cout) * 2 * N.L[l].cout;
+            double* base_s = (double*)c.take(tot * 4);
+            p.slots_bytes = 2 * tot * sizeof(double);
+            size_t off = 0;
+            for (int l = 0; l < nb; ++l) {
+                p.slots[l] = base_s ? base_s + off : nullptr;
+                p.bslots[l] = base_s ? base_s + tot + off : nullptr;
+                off += (size_t)fv_ew_bn_stat_slots(N.L[l].cout) * 2 * N.L[l].cout;
+            }
+        }
         p.dyp = c.take((size_t)B * G * G * HEAD_PAD);
         for (int i = 0; i < 2; ++i) p.G[i] = c.take(max_act);   // activation gradients (ping-pong + kept block gradient)
         for (int i = 0; i < 2; ++i) p.D[i] = c.take(max_act);   // dz of layer l lives in D[l&1] until its wgrad has run
@@ -267,6 +277,7 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
     const int S = image_size;
 
     FV_HIP(ctx, hipMemsetAsync(grads, 0, (size_t)N.nparam * sizeof(float), ctx->stream));
+    FV_HIP(ctx, hipMemsetAsync(p.slots[0], 0, p.slots_bytes, ctx->stream));   // forward and backward accumulators
     // weight images for this step: packed first layer, transposed kernels for the data-gradients
     if (int rc = fv_ew_pad_rows(ctx, params + N.L[0].w_off, p.w0p, 32, 27, 32)) return rc;
     {
@@ -288,12 +299,15 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
         const long long rows = (long long)batch * Ho * Ho;
         if (d.role == 1) skip = cur;
         const float* w = l == 0 ? p.w0p : params + d.w_off;
+        // the column sums go to fp64 accumulator slots and the normalise pass reduces them itself: two
+        // launches per layer (the per-operator API keeps the partial-row form + fv_bn_finalize)
+        const int ns = fv_ew_bn_stat_slots(d.cout);
         if (int rc = fv_op_conv_forward(ctx, cur, w, batch, H, H, d.cin, d.cout, d.ksize, d.stride, FV_EPI_STATS, nullptr, nullptr,
-                                        0.f, nullptr, p.z[l], p.psum, p.psq)) return rc;
-        if (int rc = fv_ew_bn_finalize(ctx, p.psum, p.psq, fv_conv_mtiles((int)rows, d.cout), d.cout, (double)rows,
-                                       params + d.gamma_off, params + d.beta_off, BN_EPS, BN_MOMENTUM, p.mean[l], p.invstd[l],
-                                       p.scale[l], p.shift[l], bn_state + d.mean_off, bn_state + d.var_off)) return rc;
-        if (int rc = fv_ew_bn_act(ctx, p.z[l], p.scale[l], p.shift[l], d.role == 2 ? skip : nullptr, p.a[l], rows, d.cout, LEAKY)) return rc;
+                                        0.f, nullptr, p.z[l], nullptr, nullptr, 1, p.slots[l], ns)) return rc;
+        if (int rc = fv_ew_bn_act_stats(ctx, p.z[l], p.slots[l], ns, (double)rows, params + d.gamma_off, params + d.beta_off,
+                                        BN_EPS, BN_MOMENTUM, p.mean[l], p.invstd[l], p.scale[l], p.shift[l],
+                                        bn_state + d.mean_off, bn_state + d.var_off, d.role == 2 ? skip : nullptr, p.a[l], rows,
+                                        d.cout, LEAKY)) return rc;
         cur = p.a[l];
     }
     const auto& h = N.L[nb];
@@ -333,7 +347,7 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
         float* dz = p.D[par];
         if (d.role == 2) ires = ig;  // add(skip, x): the same gradient also reaches the skip input
         if (int rc = fv_ew_bn_bwd(ctx, p.G[ig], p.z[l], p.scale[l], p.shift[l], p.mean[l], p.invstd[l], rows, d.cout, LEAKY,
-                                  p.pdb, p.pdg, grads + d.beta_off, grads + d.gamma_off, dz)) return rc;
+                                  nullptr, nullptr, grads + d.beta_off, grads + d.gamma_off, dz, p.bslots[l], fv_ew_bn_stat_slots(d.cout))) return rc;
         const float* xin = l == 0 ? x : p.a[l - 1];
         const int64_t cnt = (int64_t)d.cout * d.ksize * d.ksize * d.cin + 2 * d.cout;
         if (ov) {

@@ -13,7 +13,7 @@ static void fwd_taps(int ksize, FvTaps& t) {
 
 int fv_op_conv_forward(fv_ctx* ctx, const float* x, const float* w, int B, int H, int W, int cin, int cout, int ksize,
                        int stride, int epi, const float* scale, const float* shift, float leaky, const float* addend,
-                       float* out, float* psum, float* psq, int ksplit) {
+                       float* out, float* psum, float* psq, int ksplit, double* stat_slots, int stat_nslot) {
     FV_REQUIRE(ctx, (ksize == 1 && stride == 1) || (ksize == 3 && (stride == 1 || stride == 2)), "conv: unsupported k=%d s=%d", ksize, stride);
     FV_REQUIRE(ctx, H % stride == 0 && W % stride == 0, "conv: H,W must be divisible by the stride");
     FvConvArgs a{};
@@ -26,6 +26,7 @@ int fv_op_conv_forward(fv_ctx* ctx, const float* x, const float* w, int B, int H
     if (cin % 32 != 0) a.Tw = 1;  // packed [cout][32] first-layer weights
     a.alg_flops = 2.0 * a.M * cout * (double)(ksize * ksize * cin);
     a.ksplit = ksplit; a.split_stride = (long long)a.M * cout;
+    a.stat_slots = stat_slots; a.stat_nslot = stat_nslot;
     return fv_conv_launch(ctx, a);
 }
 
