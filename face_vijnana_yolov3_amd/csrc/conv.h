@@ -11,7 +11,7 @@ struct FvTaps {
     int wslot[9];
 };
 
-enum { FV_EPI_AFFINE = 1, FV_EPI_LEAKY = 2, FV_EPI_ADD = 4, FV_EPI_STATS = 8 };
+enum { FV_EPI_AFFINE = 1, FV_EPI_LEAKY = 2, FV_EPI_ADD = 4, FV_EPI_STATS = 8, FV_EPI_BNRED = 16 };
 
 // Gather-convolution:  out[b, oh*os+oph, ow*os+opw, n] = sum_{t,c} x[b, oh*is+dh[t], ow*is+dw[t], c] * w[n][wslot[t]][c]
 // over the output lattice (B, Hl, Wl); out-of-range input pixels read as zero.  This one form
@@ -28,6 +28,12 @@ struct FvConvArgs {
     float* psq;           //                and of its squares
     double* stat_slots;   // FV_EPI_STATS, alternative to psum/psq: [stat_nslot][2][Nout] accumulators (sum, sum of
     int stat_nslot;       //   squares); tile mt ADDS its column sums to slot mt % stat_nslot (fp64 atomics)
+    // FV_EPI_BNRED: the result is the gradient w.r.t. the output of a BN+LeakyReLU layer whose pre-BN tensor is bn_z
+    // (same layout as out); the epilogue adds that layer's d-beta / d-gamma column sums to bn_slots [bn_nslot][2][Nout]
+    const float *bn_z, *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
+    double* bn_slots;
+    int bn_nslot;
+    float bn_leaky;
     int B, Hin, Win, Cin;
     int Hl, Wl;
     int Hout, Wout, Nout;

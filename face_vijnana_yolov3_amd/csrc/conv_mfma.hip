@@ -32,6 +32,49 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + pos;
 }
 
+// Fused BatchNorm-backward reduction (FV_EPI_BNRED): the tile just produced is the gradient g w.r.t. the
+// OUTPUT of a BN+LeakyReLU layer; with that layer's pre-BN tensor z the epilogue also forms
+// gy = g * leaky'(z*scale+shift) and accumulates the column sums of gy and gy * xhat (d-beta, d-gamma)
+// into that layer's fp64 slots -- the separate reduction pass over (g, z) disappears.
+struct BnRedAcc {
+    float4 sc, sh, mu, is, db, dg;
+    __device__ __forceinline__ void init(const FvConvArgs& a, int n, bool on) {
+        db = make_float4(0.f, 0.f, 0.f, 0.f); dg = db;
+        sc = sh = mu = is = db;
+        if (on) {
+            sc = *reinterpret_cast<const float4*>(a.bn_scale + n); sh = *reinterpret_cast<const float4*>(a.bn_shift + n);
+            mu = *reinterpret_cast<const float4*>(a.bn_mean + n); is = *reinterpret_cast<const float4*>(a.bn_invstd + n);
+        }
+    }
+    __device__ __forceinline__ void add(const float4& g, const float4& z, float leaky) {
+        float gy;
+        gy = (z.x * sc.x + sh.x) > 0.f ? g.x : g.x * leaky; db.x += gy; dg.x += gy * ((z.x - mu.x) * is.x);
+        gy = (z.y * sc.y + sh.y) > 0.f ? g.y : g.y * leaky; db.y += gy; dg.y += gy * ((z.y - mu.y) * is.y);
+        gy = (z.z * sc.z + sh.z) > 0.f ? g.z : g.z * leaky; db.z += gy; dg.z += gy * ((z.z - mu.z) * is.z);
+        gy = (z.w * sc.w + sh.w) > 0.f ? g.w : g.w * leaky; db.w += gy; dg.w += gy * ((z.w - mu.w) * is.w);
+    }
+};
+// reduce the per-thread sums over the RL row lanes through LDS (scratch: 2 * RL * BN floats) and add the
+// tile's column sums to slot `row_id % nslot`
+template <int BN, int NTH>
+__device__ __forceinline__ void bnred_flush(const FvConvArgs& a, const BnRedAcc& r, float* scratch, int n0, int row_id) {
+    constexpr int C4 = BN / 4, RL = NTH / C4;
+    const int tid = threadIdx.x, c4 = (tid % C4) * 4, rl = tid / C4;
+    float (*red)[RL][BN] = reinterpret_cast<float (*)[RL][BN]>(scratch);
+    __syncthreads();
+    *reinterpret_cast<float4*>(&red[0][rl][c4]) = r.db;
+    *reinterpret_cast<float4*>(&red[1][rl][c4]) = r.dg;
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.Nout) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < RL; ++w) { s += red[0][w][tid]; q += red[1][w][tid]; }
+        double* sl = a.bn_slots + (size_t)(row_id % a.bn_nslot) * 2 * a.Nout;
+        unsafeAtomicAdd(sl + n0 + tid, (double)s);
+        unsafeAtomicAdd(sl + a.Nout + n0 + tid, (double)q);
+    }
+}
+
 // Column sum / sum of squares of one tile: either its own partial row (deterministic; reduced later by
 // bn_finalize) or added to one of a few fp64 accumulator slots (fp32 partials are exact in fp64; only
 // the order of the fp64 additions varies, far below fp32 resolution) which the consumer kernel sums
@@ -56,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
 
     // one block: A double buffer, B double buffer; reused as the BM x BN output tile by the epilogue
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDT];
-    static_assert(2 * (BM + BN) * LDT >= BM * BN, "operand LDS must hold the output tile");
+    static_assert(2 * (BM + BN) * LDT >= BM * BN + 2 * (256 / (BN / 4)) * BN, "operand LDS must hold the output tile + the BN-backward reduction scratch");
     float (*As)[BM * LDT] = reinterpret_cast<float (*)[BM * LDT]>(smem);
     float (*Bs)[BN * LDT] = reinterpret_cast<float (*)[BN * LDT]>(smem + 2 * BM * LDT);
     __shared__ int rowoff[BM];
@@ -350,11 +393,16 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
         __syncthreads();
         constexpr int C4 = BN / 4;                   // float4 pieces per tile row
         float* outp = a.out + (size_t)blockIdx.y * a.split_stride;
+        const bool bnred = (a.epi & FV_EPI_BNRED) != 0;
+        BnRedAcc br;                                 // 256 % C4 == 0: a thread keeps its 4 columns over the rows
+        br.init(a, n0 + (tid % C4) * 4, bnred && n0 + (tid % C4) * 4 < a.Nout);
 #pragma unroll
         for (int p = 0; p < BM * C4 / 256; ++p) {
             const int f = tid + 256 * p, row = f / C4, c4 = (f % C4) * 4;
             const int off = rowoff[row], n = n0 + c4;
             if (off >= 0 && n < a.Nout) {
+                float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bnred) zv = *reinterpret_cast<const float4*>(a.bn_z + off + n);
                 float4 v = *reinterpret_cast<const float4*>(&Cs[row * BN + c4]);
                 if (a.epi & FV_EPI_AFFINE) {
                     if (a.scale) { const float4 s = *reinterpret_cast<const float4*>(a.scale + n); v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w; }
@@ -369,8 +417,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
                     v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
                 }
                 *reinterpret_cast<float4*>(outp + off + n) = v;
+                if (bnred) br.add(v, zv, a.bn_leaky);
             }
         }
+        if (bnred) bnred_flush<BN, 256>(a, br, smem + BM * BN, n0, mt + cls * (int)(gridDim.x / NT));
         return;
     }
     // scalar path: output rows that are not 16-byte aligned (head: 6 channels; 255-channel detection convs)
@@ -431,9 +481,14 @@ __global__ __launch_bounds__(1024) void conv_tail_fixup_kernel(const FvConvArgs 
     const int n = n0 + c4;
     const float4* slab = reinterpret_cast<const float4*>(a.tail_slab + (size_t)blockIdx.x * a.tail_f * (BM * BN));
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
+    const bool bnred = (a.epi & FV_EPI_BNRED) != 0;
+    BnRedAcc br;
+    br.init(a, n, bnred && n < a.Nout);
 #pragma unroll
     for (int p = 0; p < BM * C4 / NTH; ++p) {
         const int f = tid + NTH * p, row = f / C4;
+        float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bnred && rowoff[row] >= 0 && n < a.Nout) zv = *reinterpret_cast<const float4*>(a.bn_z + rowoff[row] + n);
         float4 v = slab[f];
         for (int k = 1; k < a.tail_f; ++k) {
             const float4 u = slab[(size_t)k * (BM * BN / 4) + f];
@@ -456,8 +511,10 @@ __global__ __launch_bounds__(1024) void conv_tail_fixup_kernel(const FvConvArgs 
                 v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
             }
             *reinterpret_cast<float4*>(a.out + off + n) = v;
+            if (bnred) br.add(v, zv, a.bn_leaky);
         }
     }
+    if (bnred) bnred_flush<BN, NTH>(a, br, &red[0][0][0], n0, mt);
     if (a.epi & FV_EPI_STATS) {
         // rows outside the problem are zero in every slice, so they add nothing
         *reinterpret_cast<float4*>(&red[0][rl][c4]) = cs;
@@ -761,6 +818,10 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
     FV_REQUIRE(ctx, !(a.epi & FV_EPI_STATS) || (((a.psum && a.psq) || (a.stat_slots && a.stat_nslot >= 1)) && a.nclass == 1),
                "conv: stats need psum/psq or accumulator slots");
     FV_REQUIRE(ctx, !(a.epi & FV_EPI_ADD) || a.addend, "conv: FV_EPI_ADD needs addend");
+    FV_REQUIRE(ctx, !(a.epi & FV_EPI_BNRED) || (a.bn_z && a.bn_scale && a.bn_shift && a.bn_mean && a.bn_invstd && a.bn_slots &&
+                                                 a.bn_nslot >= 1 && (a.Nout & 3) == 0 && a.ksplit <= 1 && !ctx->conv_dma &&
+                                                 !(a.epi & (FV_EPI_STATS | FV_EPI_AFFINE | FV_EPI_LEAKY))),
+               "conv: fused BN-backward reduction needs its layer's tensors, 16-byte rows and a plain (+add) epilogue");
     FV_REQUIRE(ctx, a.ksplit <= 1 || (a.epi == 0 && a.nclass == 1 && a.Cin % BK == 0), "conv: split-K stores raw partials only");
     const bool gather = a.Cin % BK != 0;
     if (gather) {

@@ -12,7 +12,7 @@ int fv_ew_bn_act(fv_ctx* ctx, const float* z, const float* scale, const float* s
 int fv_ew_bn_bwd_chunks(long long rows, int C);
 int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale, const float* shift, const float* mean,
                  const float* invstd, long long rows, int C, float leaky, float* pdb, float* pdg, float* dbeta, float* dgamma,
-                 float* dz, double* slots = nullptr, int nslot = 0);
+                 float* dz, double* slots = nullptr, int nslot = 0, bool reduced = false);
 int fv_ew_mse(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int Cpad, float* loss, float* dy, float* dbias);
 int fv_ew_adam(fv_ctx* ctx, float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2, float eps);
 // training-mode BN without a finalize launch: the conv epilogue adds its column sums to

@@ -553,13 +553,14 @@ int fv_ew_bn_bwd_chunks(long long rows, int C) {
 
 int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale, const float* shift, const float* mean,
                  const float* invstd, long long rows, int C, float leaky, float* pdb, float* pdg, float* dbeta, float* dgamma,
-                 float* dz, double* slots, int nslot) {
+                 float* dz, double* slots, int nslot, bool reduced) {
     FV_REQUIRE(ctx, C % 4 == 0, "bn_bwd: C must be a multiple of 4");
+    FV_REQUIRE(ctx, !reduced || slots, "bn_bwd: a reduction done elsewhere must have gone to accumulator slots");
     FV_REQUIRE(ctx, !slots || (nslot >= 1 && C <= 1024 && (C >= 256 || 256 % C == 0)), "bn_bwd: accumulator slots need C <= 1024 dividing or divided by 256");
     long long rpb = (rows + 2047) / 2048;
     if (rpb < 64) rpb = 64;
     int chunks = (int)((rows + rpb - 1) / rpb);
-    {
+    if (!reduced) {
         FvProfScope ps(ctx, "bn_bwd_reduce_kernel", 0.0, 8.0 * rows * C);
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(chunks), dim3(256), 0, ctx->stream, g, z, scale, shift, mean, invstd, rows, C,
                            (int)rpb, leaky, pdb, pdg, slots, nslot);

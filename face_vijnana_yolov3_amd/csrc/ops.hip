@@ -31,7 +31,7 @@ int fv_op_conv_forward(fv_ctx* ctx, const float* x, const float* w, int B, int H
 }
 
 int fv_op_conv_dgrad(fv_ctx* ctx, const float* dy, const float* w_t, int B, int H, int W, int cin, int cout_pad, int ksize,
-                     int stride, const float* addend, float* dx) {
+                     int stride, const float* addend, float* dx, const FvBnRed* bn) {
     FV_REQUIRE(ctx, (ksize == 1 && stride == 1) || (ksize == 3 && (stride == 1 || stride == 2)), "dgrad: unsupported k=%d s=%d", ksize, stride);
     FV_REQUIRE(ctx, cout_pad % 32 == 0, "dgrad: cout_pad must be a multiple of 32");
     FV_REQUIRE(ctx, H % stride == 0 && W % stride == 0, "dgrad: H,W must be divisible by the stride");
@@ -41,6 +41,11 @@ int fv_op_conv_dgrad(fv_ctx* ctx, const float* dy, const float* w_t, int B, int 
     a.Hout = H; a.Wout = W; a.Nout = cin;
     a.is = 1; a.Tw = ksize * ksize;
     a.epi = addend ? FV_EPI_ADD : 0; a.leaky = 0.f;
+    if (bn) {
+        a.epi |= FV_EPI_BNRED;
+        a.bn_z = bn->z; a.bn_scale = bn->scale; a.bn_shift = bn->shift; a.bn_mean = bn->mean; a.bn_invstd = bn->invstd;
+        a.bn_slots = bn->slots; a.bn_nslot = bn->nslot; a.bn_leaky = bn->leaky;
+    }
     if (stride == 1) {
         a.Hl = H; a.Wl = W; a.os = 1; a.nclass = 1;
         FvTaps& t = a.taps[0];
@@ -115,7 +120,7 @@ int fv_conv2d_forward(fv_ctx* ctx, const float* x, const float* w, int B, int H,
 int fv_conv2d_dgrad(fv_ctx* ctx, const float* dy, const float* w_t, int B, int H, int W, int cin, int cout_pad, int ksize,
                     int stride, const float* addend, float* dx) {
     if (!ctx) return FV_ERR_INVALID;
-    return fv_op_conv_dgrad(ctx, dy, w_t, B, H, W, cin, cout_pad, ksize, stride, addend, dx);
+    return fv_op_conv_dgrad(ctx, dy, w_t, B, H, W, cin, cout_pad, ksize, stride, addend, dx, nullptr);
 }
 
 int fv_conv2d_wgrad(fv_ctx* ctx, const float* x, const float* dy, int B, int H, int W, int cin, int cout, int dy_stride,
