@@ -2,7 +2,9 @@
 // LeakyReLU / residual add (reference yolov3_detect.py:212-215), their backward, the MSE loss and
 // its gradient (reference face_detection.py:381), the Keras-formula Adam update
 // (face_detection.py:376-379) and the weight-layout transforms the data-gradient needs.
-// All tensors NHWC float32; 16-byte vector accesses; deterministic reductions (no float atomics).
+// All tensors NHWC float32; 16-byte vector accesses; reductions in fixed order, except the BN accumulator
+// slots of the training step, which are filled with fp64 atomics (fp32 partials are exact in fp64; only
+// the order of the fp64 additions varies, far below fp32 resolution -- see DESIGN.md 4.3).
 #include "elementwise.h"
 
 namespace {

@@ -133,7 +133,10 @@ typedef void (*fv_bucket_fn)(void* user, int64_t offset, int64_t count);
  * model.fit_generator runs per batch (fd.py:621-627) with loss='mse' (fd.py:381): training-mode BN
  * (batch statistics, moving statistics updated in bn_state), mean-squared error over every element
  * of [batch][G][G][6], gradients of all 40 640 230 parameters written to `grads` (overwritten).
- * loss: one float (device).  Follow with fv_adam_step. */
+ * loss: one float (device).  Follow with fv_adam_step.
+ * Reproducibility: kernel gradients are accumulated with float atomics and the BN statistics with fp64
+ * atomics, so two runs agree to rounding (dW ~3e-6 relative, statistics in the last float bit at most),
+ * not bit for bit; fv_forward_infer is bit-reproducible. */
 int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float* x, const float* y_true,
                   int batch, int image_size, void* workspace, size_t workspace_bytes, float* grads,
                   float* loss, fv_bucket_fn on_bucket, void* user);
