@@ -74,6 +74,7 @@ def _declare(L):
         'fv_workspace_bytes': (sz, [i32, i32, i32]),
         'fv_forward_infer': (i32, [vp, vp, vp, vp, i32, i32, vp, sz, vp]),
         'fv_train_step': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, vp, BUCKET_FN, vp]),
+        'fv_train_workspace_tensor': (i32, [i32, i32, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(i64)]),
         'fv_adam_step': (i32, [vp, vp, vp, vp, vp, i64, i64, f64, f64, f64, f64, f64]),
         'fv_conv2d_forward': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp]),
         'fv_conv2d_stat_rows': (i32, [i64]),
@@ -85,9 +86,16 @@ def _declare(L):
         'fv_bn_act': (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32]),
         'fv_bn_bwd_scratch_floats': (i64, [i64, i32]),
         'fv_bn_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp, vp, vp, vp]),
+        'fv_bn_stat_slots': (i32, [i32]),
+        'fv_conv2d_forward_slots': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32]),
+        'fv_bn_act_slots': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, f32]),
+        'fv_conv2d_dgrad_bnred': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, i32]),
+        'fv_bn_bwd_slots': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp, i32, i32, vp, vp, vp]),
         'fv_mse_loss_grad': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
         'fv_fd_loss_grad': (i32, [vp, vp, vp, i32, i32, vp, vp]),
         'fv_letterbox': (i32, [vp, vp, i32, i32, i32, vp, ctypes.POINTER(ctypes.c_int32)]),
+        'fv_letterbox_batch': (i32, [vp, vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), i32, i32, vp,
+                                    ctypes.POINTER(ctypes.c_int32)]),
         'fv_yolov3_num_layers': (i32, []),
         'fv_yolov3_layer': (i32, [i32, i32, ctypes.POINTER(LayerDesc)]),
         'fv_yolov3_param_count': (i64, [i32]),

@@ -202,6 +202,22 @@ size_t fv_workspace_bytes(int batch, int image_size, int training) {
     return make_plan(nullptr, batch, image_size, training != 0).bytes;
 }
 
+int fv_train_workspace_tensor(int batch, int image_size, int layer, int which, size_t* offset_bytes, int64_t* count) {
+    if (!offset_bytes || !count || batch < 1 || image_size < 32 || image_size % 32) return FV_ERR_INVALID;
+    const Net& N = net();
+    const int nb = (int)N.L.size() - 1;
+    if (layer < 0 || layer >= nb || which < 0 || which > 5) return FV_ERR_INVALID;
+    char* const base = (char*)(uintptr_t)65536;   // any non-null base: only differences are used
+    Plan p = make_plan(base, batch, image_size, true);
+    const auto& d = N.L[layer];
+    const int Ho = image_size / d.out_div;
+    const float* t = which == 0 ? p.z[layer] : which == 1 ? p.a[layer] : which == 2 ? p.mean[layer]
+                   : which == 3 ? p.invstd[layer] : which == 4 ? p.scale[layer] : p.shift[layer];
+    *offset_bytes = (size_t)((const char*)t - base);
+    *count = which <= 1 ? (int64_t)batch * Ho * Ho * d.cout : d.cout;
+    return FV_OK;
+}
+
 int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, const float* x, int batch, int image_size,
                      void* workspace, size_t workspace_bytes, float* y) {
     if (!ctx) return FV_ERR_INVALID;

@@ -164,6 +164,51 @@ int fv_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale, c
     return fv_ew_bn_bwd(ctx, g, z, scale, shift, mean, invstd, rows, C, leaky, scratch, scratch + half, dbeta, dgamma, dz);
 }
 
+int fv_bn_stat_slots(int C) { return fv_ew_bn_stat_slots(C); }
+
+static int slots_ok(fv_ctx* ctx, const double* slots, int nslot, int C, const char* who) {
+    FV_REQUIRE(ctx, slots && nslot >= 1 && C % 4 == 0 && C <= 1024 && (C >= 256 ? true : 256 % C == 0),
+               "%s: needs accumulator slots, C %% 4 == 0, C <= 1024 and C dividing or divided by 256 (C=%d)", who, C);
+    return FV_OK;
+}
+
+int fv_conv2d_forward_slots(fv_ctx* ctx, const float* x, const float* w, int B, int H, int W, int cin, int cout, int ksize,
+                            int stride, float* z, double* slots, int nslot) {
+    if (!ctx) return FV_ERR_INVALID;
+    if (int rc = slots_ok(ctx, slots, nslot, cout, "conv2d_forward_slots")) return rc;
+    return fv_op_conv_forward(ctx, x, w, B, H, W, cin, cout, ksize, stride, FV_EPI_STATS, nullptr, nullptr, 0.f, nullptr, z,
+                              nullptr, nullptr, 1, slots, nslot);
+}
+
+int fv_bn_act_slots(fv_ctx* ctx, const float* z, const double* slots, int nslot, int64_t rows, int C, const float* gamma,
+                    const float* beta, float eps, float momentum, float* mean, float* invstd, float* scale, float* shift,
+                    float* moving_mean, float* moving_var, const float* skip, float* out, float leaky) {
+    if (!ctx) return FV_ERR_INVALID;
+    if (int rc = slots_ok(ctx, slots, nslot, C, "bn_act_slots")) return rc;
+    FV_REQUIRE(ctx, z && gamma && beta && mean && invstd && scale && shift && out && rows > 0, "bn_act_slots: NULL buffer");
+    return fv_ew_bn_act_stats(ctx, z, slots, nslot, (double)rows, gamma, beta, eps, momentum, mean, invstd, scale, shift,
+                              moving_mean, moving_var, skip, out, rows, C, leaky);
+}
+
+int fv_conv2d_dgrad_bnred(fv_ctx* ctx, const float* dy, const float* w_t, int B, int H, int W, int cin, int cout_pad, int ksize,
+                          int stride, const float* addend, float* dx, const float* bn_z, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, float leaky, double* slots, int nslot) {
+    if (!ctx) return FV_ERR_INVALID;
+    if (int rc = slots_ok(ctx, slots, nslot, cin, "conv2d_dgrad_bnred")) return rc;
+    FvBnRed b{bn_z, scale, shift, mean, invstd, slots, nslot, leaky};
+    return fv_op_conv_dgrad(ctx, dy, w_t, B, H, W, cin, cout_pad, ksize, stride, addend, dx, &b);
+}
+
+int fv_bn_bwd_slots(fv_ctx* ctx, const float* g, const float* z, const float* scale, const float* shift, const float* mean,
+                    const float* invstd, int64_t rows, int C, float leaky, double* slots, int nslot, int reduced, float* dbeta,
+                    float* dgamma, float* dz) {
+    if (!ctx) return FV_ERR_INVALID;
+    if (int rc = slots_ok(ctx, slots, nslot, C, "bn_bwd_slots")) return rc;
+    FV_REQUIRE(ctx, g && z && scale && shift && mean && invstd && dbeta && dgamma && dz && rows > 0, "bn_bwd_slots: NULL buffer");
+    return fv_ew_bn_bwd(ctx, g, z, scale, shift, mean, invstd, rows, C, leaky, nullptr, nullptr, dbeta, dgamma, dz, slots, nslot,
+                        reduced != 0);
+}
+
 int fv_mse_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int c_pad, float* loss, float* dy,
                      float* dbias) {
     if (!ctx) return FV_ERR_INVALID;

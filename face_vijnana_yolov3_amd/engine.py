@@ -112,15 +112,53 @@ class Engine(object):
         B, S = x.shape[0], x.shape[1]
         assert y_true.shape == (B, S // 32, S // 32, HEAD_C), y_true.shape
         ws = self._workspace(B, S, True)
+        cb_error = []
         if on_bucket is not None:
-            cb = BUCKET_FN(lambda user, off, cnt: on_bucket(int(off), int(cnt)))
+            def _cb(user, off, cnt):
+                # an exception raised inside a ctypes callback is printed and swallowed: keep the first one
+                # and re-raise it once fv_train_step has returned (later ranges are not forwarded)
+                if cb_error:
+                    return
+                try:
+                    on_bucket(int(off), int(cnt))
+                except BaseException as e:   # noqa: B902
+                    cb_error.append(e)
+            cb = BUCKET_FN(_cb)
         else:
             cb = ctypes.cast(None, BUCKET_FN)
         self._bucket_cb = cb  # keep alive during the call
         rc = lib().fv_train_step(self.ctx.handle, ptr(self.params), ptr(self.state), ptr(x), ptr(y_true), B, S, ptr(ws),
                                  ws.numel(), ptr(self.grads), ptr(self._loss), cb, None)
         self.ctx.check(rc, 'fv_train_step')
+        if cb_error:
+            raise cb_error[0]
         return self._loss
+
+    def train_tensor(self, batch, image_size, layer, which):
+        """View into the training workspace after forward_backward (fv_train_workspace_tensor):
+        which = 'z' | 'a' | 'mean' | 'invstd' | 'scale' | 'shift' of base layer `layer`."""
+        code = {'z': 0, 'a': 1, 'mean': 2, 'invstd': 3, 'scale': 4, 'shift': 5}[which]
+        off, cnt = ctypes.c_size_t(0), ctypes.c_int64(0)
+        rc = lib().fv_train_workspace_tensor(batch, image_size, layer, code, ctypes.byref(off), ctypes.byref(cnt))
+        if rc != 0:
+            raise FvError('fv_train_workspace_tensor(%d, %d, %d, %s) failed' % (batch, image_size, layer, which))
+        ws = self._workspace(batch, image_size, True)
+        t = ws[off.value:off.value + 4 * cnt.value].view(torch.float32)
+        d = self.layers[layer]
+        if code <= 1:
+            g = image_size // d['out_div']
+            t = t.view(batch, g, g, d['cout'])
+        return t
+
+    def leaky_slopes_taken(self, batch, image_size):
+        """Per base layer, a bool tensor [B][H][W][C]: True where the last train step took the
+        positive LeakyReLU branch, i.e. fl(fl(z*scale)+shift) > 0 -- the decision every kernel of the
+        step makes (the library is built with -ffp-contract=off)."""
+        out = []
+        for l in range(len(self.layers) - 1):
+            z = self.train_tensor(batch, image_size, l, 'z')
+            out.append((z * self.train_tensor(batch, image_size, l, 'scale') + self.train_tensor(batch, image_size, l, 'shift')) > 0)
+        return out
 
     def adam_step(self, lr, beta_1, beta_2, decay=0.0, eps=1e-7):
         rc = lib().fv_adam_step(self.ctx.handle, ptr(self.params), ptr(self.grads), ptr(self.m), ptr(self.v), self.n_params,

@@ -22,7 +22,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import data
-from .postproc import BoundBox, decode_nms, letterbox_device, to_boundboxes
+from .postproc import BoundBox, decode_nms, letterbox_batch_device, letterbox_device, pack_images, to_boundboxes
 
 DEBUG = True
 
@@ -96,35 +96,49 @@ class FaceDetector(object):
     # ------------------------------------------------------------------ train (fd.py:602-630)
     def train(self):
         import torch
-        from .parallel import DataParallelTrainer
+        from .parallel import DataParallelTrainer, slice_batch
         seq = self.TrainingSequence(self.raw_data_path, self.hps, self.nn_arch, self.grid, self.cell_image_size)
         trainer = DataParallelTrainer(self.model, world_size=self.world, rank=self.rank)
         hp = self.hps
         steps = len(seq)
         rng = np.random.default_rng(0)
-        pool = ThreadPoolExecutor(max_workers=4)
+        pool = ThreadPoolExecutor(max_workers=int(hp.get('loader_threads', 8)))
+
+        def load(index):
+            """Loader side (host threads, as the reference's Keras Sequence workers): this rank's tower
+            slice of the batch -- JPEG decode, GT encoding, and the decoded images packed back to back
+            in one pinned buffer; the letterbox itself runs on the device in one launch."""
+            names = seq.file_names[index * seq.batch_size:(index + 1) * seq.batch_size]
+            sl = slice_batch(len(names), self.world, self.rank) if self.world > 1 else (0, len(names), 1.0)
+            if sl is None:
+                return None            # fewer images than ranks: skipped on every rank alike
+            lo, hi, weight = sl
+            raws = list(pool.map(lambda nm: seq.loader(os.path.join(seq.raw_data_path, nm)), names[lo:hi]))
+            y = np.asarray([data.encode_gt(seq.groups[nm].iloc[:, 3:7].values, r.shape[0], r.shape[1], seq.image_size, seq.grid,
+                                           seq.nn_arch['bb_info_c_size']) for nm, r in zip(names[lo:hi], raws)], np.float32)
+            return pack_images(raws), torch.from_numpy(y).pin_memory(), weight
+
+        feeder = ThreadPoolExecutor(max_workers=1)
         for epoch in range(hp['epochs']):
             order = rng.permutation(steps)  # Keras fit_generator shuffles batch order (shuffle=True)
             if self.rank == 0:
                 print('Epoch %d/%d' % (epoch + 1, hp['epochs']))
-            # loader threads only decode JPEGs + encode GT; the letterbox runs on the device
-            nxt = pool.submit(seq.get_raw, int(order[0]))
+            nxt = feeder.submit(load, int(order[0]))
             for k in range(steps):
-                raws, y = nxt.result()
+                item = nxt.result()
                 if k + 1 < steps:
-                    nxt = pool.submit(seq.get_raw, int(order[k + 1]))
-                if self.world > 1:  # contiguous tower slices, remainder to the last (multi_gpu_model)
-                    per = len(raws) // self.world
-                    lo = self.rank * per
-                    hi = len(raws) if self.rank == self.world - 1 else lo + per
-                    raws, y = raws[lo:hi], y[lo:hi]
-                x = torch.empty((len(raws), self.image_size, self.image_size, 3), dtype=torch.float32, device=self.model.dev)
-                for b, raw in enumerate(raws):
-                    letterbox_device(self.model.ctx, raw, self.image_size, out=x[b])
-                loss = trainer.train_on_batch(x, torch.from_numpy(y), hp['lr'], hp['beta_1'],
-                                              hp['beta_2'], hp.get('decay', 0.0))
-                if self.rank == 0:
+                    nxt = feeder.submit(load, int(order[k + 1]))   # decode of batch k+1 overlaps step k
+                if item is None:
+                    if self.rank == 0:
+                        print('%d/%d - skipped (fewer images than ranks)' % (k + 1, steps))
+                    continue
+                packed, y, weight = item
+                x, _ = letterbox_batch_device(self.model.ctx, None, self.image_size, self.model.dev, packed=packed)
+                loss = trainer.train_on_batch(x, y.to(self.model.dev, non_blocking=True), hp['lr'], hp['beta_1'],
+                                              hp['beta_2'], hp.get('decay', 0.0), weight=weight)
+                if self.rank == 0 and (DEBUG or k + 1 == steps):
                     print('%d/%d - loss: %.4f' % (k + 1, steps, float(loss.item())))
+        feeder.shutdown()
         pool.shutdown()
         if self.rank == 0:
             print('Save the model.')
@@ -188,16 +202,15 @@ class FaceDetector(object):
         test_path = self.conf['test_path']
         out_path = self.conf['output_file_path']
         res_dir = os.path.join(test_path, 'results')
-        if self.rank == 0:
-            shutil.rmtree(res_dir, ignore_errors=True)
-        os.makedirs(res_dir, exist_ok=True)
+        from .parallel import ensure_process_group, merge_rank_files, part_path, reset_dir_before_shards
+        if self.world > 1:
+            ensure_process_group(self.model.dev)
+        reset_dir_before_shards(res_dir, self.rank)     # rank 0 empties it BEFORE any rank writes into it
         gt_df = pd.read_csv(os.path.join(test_path, 'validation.csv'))
         groups = {k: v for k, v in gt_df.groupby('FILE')}
         files = self._files(test_path)
         ratios = []
-        if self.world > 1:
-            out_path = out_path + '.rank%d' % self.rank
-        with open(out_path, 'w') as f:
+        with open(part_path(out_path, self.world, self.rank), 'w') as f:
             for n, file_name in enumerate(files):
                 if DEBUG:
                     print(n + 1, '/', len(files), file_name)
@@ -224,20 +237,30 @@ class FaceDetector(object):
                 print(new_name)
                 from PIL import Image
                 Image.fromarray(img.astype('uint8')).save(os.path.join(res_dir, new_name))
-        pd.DataFrame({'ratio': ratios}).to_csv('ratios.csv' if self.world == 1 else 'ratios.csv.rank%d' % self.rank)
+        # one 6-column solution csv and one ratios.csv, whatever the number of ranks (cal_mAP_fd reads the former)
+        merge_rank_files(out_path, self.world, self.rank)
+        if self.world == 1:
+            pd.DataFrame({'ratio': ratios}).to_csv('ratios.csv')          # fd.py:780-781
+        else:
+            pd.DataFrame({'ratio': ratios}).to_csv(part_path('ratios.csv', self.world, self.rank), index=False)
+            merge_rank_files('ratios.csv', self.world, self.rank, header_lines=1)
+            if self.rank == 0:
+                pd.read_csv('ratios.csv').to_csv('ratios.csv')          # the reference's layout: running index column
 
     def test(self):
         test_path = self.conf['test_path']
         out_path = self.conf['output_file_path']
         files = self._files(test_path)
+        from .parallel import ensure_process_group, merge_rank_files, part_path
         if self.world > 1:
-            out_path = out_path + '.rank%d' % self.rank
-        with open(out_path, 'w') as f:
+            ensure_process_group(self.model.dev)
+        with open(part_path(out_path, self.world, self.rank), 'w') as f:
             for n, file_name in enumerate(files):
                 if DEBUG:
                     print(n + 1, '/', len(files), file_name)
                 _raw, boxes = self._run_file(file_name)
                 self._write_rows(f, file_name, boxes)
+        merge_rank_files(out_path, self.world, self.rank)
 
 
 def _font():

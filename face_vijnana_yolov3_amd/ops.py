@@ -98,6 +98,60 @@ def bn_bwd(ctx, g, z, scale, shift, mean, invstd, leaky=0.1):
     return dz, dgamma, dbeta
 
 
+# ------------------------------------------------------------------ the fused slot forms fv_train_step runs
+def stat_slots(C, device):
+    """Zeroed [nslot][2][C] float64 accumulators."""
+    return torch.zeros((lib().fv_bn_stat_slots(C), 2, C), dtype=torch.float64, device=device)
+
+
+def conv2d_forward_slots(ctx, x, w, stride, slots):
+    B, H, W, cin = x.shape
+    cout, k = w.shape[0], w.shape[1]
+    wd = pack_first_layer(ctx, w) if cin % 32 else w.contiguous()
+    z = torch.empty((B, H // stride, W // stride, cout), dtype=torch.float32, device=x.device)
+    rc = lib().fv_conv2d_forward_slots(ctx.handle, ptr(x.contiguous()), ptr(wd), B, H, W, cin, cout, k, stride, ptr(z), ptr(slots),
+                                       slots.shape[0])
+    ctx.check(rc, 'fv_conv2d_forward_slots')
+    return z
+
+
+def bn_act_slots(ctx, z, slots, gamma, beta, eps=1e-3, momentum=0.99, moving_mean=None, moving_var=None, skip=None, leaky=0.1):
+    C = z.shape[-1]
+    rows = z.numel() // C
+    mk = lambda: torch.empty(C, dtype=torch.float32, device=z.device)
+    mean, invstd, scale, shift = mk(), mk(), mk(), mk()
+    out = torch.empty_like(z)
+    rc = lib().fv_bn_act_slots(ctx.handle, ptr(z), ptr(slots), slots.shape[0], rows, C, ptr(gamma), ptr(beta), eps, momentum, ptr(mean),
+                               ptr(invstd), ptr(scale), ptr(shift), _p(moving_mean), _p(moving_var), _p(skip), ptr(out), leaky)
+    ctx.check(rc, 'fv_bn_act_slots')
+    return out, mean, invstd, scale, shift
+
+
+def conv2d_dgrad_bnred(ctx, dy, w, in_hw, stride, bn_z, scale, shift, mean, invstd, slots, addend=None, leaky=0.1):
+    """dgrad + fused d-beta/d-gamma reduction of the layer that produced the conv input (adds into `slots`)."""
+    B = dy.shape[0]
+    H, W = in_hw
+    cout, k, _, cin = w.shape
+    wt = transpose_weights(ctx, w, dy.shape[3])
+    dx = torch.empty((B, H, W, cin), dtype=torch.float32, device=dy.device)
+    rc = lib().fv_conv2d_dgrad_bnred(ctx.handle, ptr(dy.contiguous()), ptr(wt), B, H, W, cin, dy.shape[3], k, stride, _p(addend), ptr(dx),
+                                     ptr(bn_z), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), leaky, ptr(slots), slots.shape[0])
+    ctx.check(rc, 'fv_conv2d_dgrad_bnred')
+    return dx
+
+
+def bn_bwd_slots(ctx, g, z, scale, shift, mean, invstd, slots, reduced, leaky=0.1):
+    C = z.shape[-1]
+    rows = z.numel() // C
+    dbeta = torch.empty(C, dtype=torch.float32, device=z.device)
+    dgamma = torch.empty_like(dbeta)
+    dz = torch.empty_like(z)
+    rc = lib().fv_bn_bwd_slots(ctx.handle, ptr(g.contiguous()), ptr(z), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), rows, C, leaky,
+                               ptr(slots), slots.shape[0], 1 if reduced else 0, ptr(dbeta), ptr(dgamma), ptr(dz))
+    ctx.check(rc, 'fv_bn_bwd_slots')
+    return dz, dgamma, dbeta
+
+
 def mse_loss_grad(ctx, yp, yt, c_pad=32):
     C = yp.shape[-1]
     rows = yp.numel() // C

@@ -8,8 +8,14 @@ layer the C ABI reports its range (fv_bucket_fn) and ranges are coalesced into b
 >= bucket_bytes that are all-reduced on a side stream while backward continues.  xGMI is
 point-to-point, so few large collectives beat many small ones: default bucket 32 MiB
 (162.56 MB of gradients -> 5-6 collectives per step).  Adam then runs redundantly on every rank
-(bit-identical weights, no broadcast)."""
+(bit-identical weights, no broadcast).
+
+Uneven slices (multi_gpu_model gives the remainder of a short last batch to the last tower): the
+merged-batch MSE is sum_r n_r/N * loss_r, so every rank scales its gradient by n_r/N before the SUM
+all-reduce; a batch with fewer images than ranks is skipped on ALL ranks (`slice_batch` returns None
+everywhere), never on some -- a rank that stayed out of a collective would hang the others."""
 import os
+import shutil
 
 import torch
 import torch.distributed as dist
@@ -59,6 +65,7 @@ class DataParallelTrainer(object):
         self.bucket_bytes = bucket_bytes
         self.comm = None
         self.reducer = None
+        self._comm_events = []
         self.bucketed = self.world > 1 or force_bucket_path  # force: exercise the stream/bucket path on 1 GPU
         if self.bucketed:
             self.comm = torch.cuda.Stream(device=engine.dev)
@@ -83,14 +90,33 @@ class DataParallelTrainer(object):
         ev.record(torch.cuda.current_stream(self.eng.dev))
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(ev)
+            view.mul_(self._weight)            # n_rank / n_total: SUM over ranks = gradient of the merged-batch mean
             if self.world > 1:
+                t0 = None
+                if self.time_comm:
+                    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+                    t0.record(self.comm)
                 dist.all_reduce(view, op=dist.ReduceOp.SUM)
-            view.mul_(1.0 / self.world)
+                if t0 is not None:
+                    t1.record(self.comm)
+                    self._comm_events.append((t0, t1))
 
-    def train_on_batch(self, x, y, lr, beta_1, beta_2, decay=0.0):
+    time_comm = False        # bench.py: bracket every collective with events on the comm stream
+    _weight = 1.0
+
+    def comm_ms(self):
+        """Sum of the all-reduce durations recorded since the last call (syncs the comm stream)."""
+        self.comm.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._comm_events)
+        self._comm_events = []
+        return ms
+
+    def train_on_batch(self, x, y, lr, beta_1, beta_2, decay=0.0, weight=None):
+        """weight: this rank's share n_rank / n_total of the merged batch (default 1 / world)."""
         eng = self.eng
         if not self.bucketed:
             return eng.train_on_batch(x, y, lr, beta_1, beta_2, decay)
+        self._weight = float(weight) if weight is not None else 1.0 / self.world
         self.reducer.reset()
         loss = eng.forward_backward(x, y, on_bucket=self.reducer.on_range)
         self.reducer.flush()
@@ -121,6 +147,67 @@ class DataParallelTrainer(object):
         if self.world > 1 and dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
+
+
+def slice_batch(n, world_size, rank):
+    """Contiguous tower slice [lo, hi) of an n-image batch, as keras.utils.multi_gpu_model cuts it
+    (fd.py:369: n // world each, the remainder to the last tower), with this rank's weight n_r / n in the
+    merged-batch mean.  None on EVERY rank when n < world (some tower would be empty)."""
+    per = n // world_size
+    if per == 0:
+        return None
+    lo = rank * per
+    hi = n if rank == world_size - 1 else lo + per
+    return lo, hi, (hi - lo) / float(n)
+
+
+def ensure_process_group(device=None):
+    """evaluate()/test() under torchrun need a barrier but no trainer: join the default group."""
+    if int(os.environ.get('WORLD_SIZE', 1)) > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        backend = os.environ.get('FV_DIST_BACKEND', 'nccl')
+        if backend == 'nccl' and device is not None:
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
+
+
+def _barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def reset_dir_before_shards(path, rank):
+    """Rank 0 empties `path`, every rank waits for that, then creates it: no rank can lose files it wrote
+    to a directory another rank is still deleting."""
+    if rank == 0:
+        shutil.rmtree(path, ignore_errors=True)
+        os.makedirs(path, exist_ok=True)
+    _barrier()
+    os.makedirs(path, exist_ok=True)
+
+
+def part_path(path, world_size, rank):
+    return path if world_size == 1 else '%s.rank%d' % (path, rank)
+
+
+def merge_rank_files(path, world_size, rank, header_lines=0):
+    """After every rank has written and closed part_path(path, ...): rank 0 concatenates the parts in rank
+    order into `path` (file shards are contiguous, so this is the single-process row order), keeping the
+    first part's `header_lines` only, and removes the parts.  Collective: all ranks must call it."""
+    if world_size == 1:
+        return
+    _barrier()
+    if rank == 0:
+        with open(path, 'w') as out:
+            for r in range(world_size):
+                with open(part_path(path, world_size, r)) as f:
+                    lines = f.readlines()
+                out.writelines(lines if r == 0 else lines[header_lines:])
+        for r in range(world_size):
+            os.remove(part_path(path, world_size, r))
+    _barrier()
 
 
 def shard_files(file_names, world_size, rank):

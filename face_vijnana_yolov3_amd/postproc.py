@@ -84,3 +84,40 @@ def letterbox_device(ctx, raw_u8, image_size, out=None):
     geom = (ctypes.c_int32 * 6)()
     ctx.check(lib().fv_letterbox(ctx.handle, ptr(t), h, w, S, ptr(out), geom), 'fv_letterbox')
     return out, (h, w, geom[2], geom[3], geom[4], geom[5])
+
+
+def pack_images(raws, pin=True):
+    """Host side of fv_letterbox_batch: the decoded uint8 images back to back in ONE (pinned) host
+    buffer -> (uint8 tensor, offsets int64 list, hw list)."""
+    import torch
+    sizes = [int(r.shape[0]) * int(r.shape[1]) * 3 for r in raws]
+    buf = torch.empty(sum(sizes), dtype=torch.uint8)
+    if pin and torch.cuda.is_available():
+        buf = buf.pin_memory()
+    view = buf.numpy()
+    offs, hw, o = [], [], 0
+    for r, n in zip(raws, sizes):
+        a = np.asarray(r, dtype=np.uint8)
+        assert a.ndim == 3 and a.shape[2] == 3
+        view[o:o + n] = a.reshape(-1)
+        offs.append(o); hw += [int(a.shape[0]), int(a.shape[1])]
+        o += n
+    return buf, offs, hw
+
+
+def letterbox_batch_device(ctx, raws, image_size, device, out=None, packed=None):
+    """list of uint8 HxWx3 arrays -> ((n,S,S,3) float32 CUDA tensor, [geometry tuples]) in ONE launch
+    (fv_letterbox_batch); `packed` = the result of pack_images when a loader thread prepared it."""
+    import ctypes
+    import torch
+    buf, offs, hw = packed if packed is not None else pack_images(raws)
+    n = len(offs)
+    S = int(image_size)
+    dbuf = buf.to(device, non_blocking=True)
+    if out is None:
+        out = torch.empty((n, S, S, 3), dtype=torch.float32, device=device)
+    geom = (ctypes.c_int32 * (6 * n))()
+    rc = lib().fv_letterbox_batch(ctx.handle, ptr(dbuf), (ctypes.c_int64 * n)(*offs), (ctypes.c_int32 * (2 * n))(*hw), n, S, ptr(out), geom)
+    ctx.check(rc, 'fv_letterbox_batch')
+    geoms = [(hw[2 * i], hw[2 * i + 1], geom[6 * i + 2], geom[6 * i + 3], geom[6 * i + 4], geom[6 * i + 5]) for i in range(n)]
+    return out, geoms

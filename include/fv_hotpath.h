@@ -141,6 +141,15 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
                   int batch, int image_size, void* workspace, size_t workspace_bytes, float* grads,
                   float* loss, fv_bucket_fn on_bucket, void* user);
 
+/* Introspection of the training workspace after fv_train_step (test aid; Keras keeps these tensors
+ * inside the TF graph): where layer `layer` (0..51) keeps which = 0 pre-BN output z, 1 activated output a
+ * ([batch][S/div][S/div][cout] each), 2 batch mean, 3 1/sqrt(var+eps), 4 scale, 5 shift ([cout] each).
+ * offset_bytes is relative to the workspace pointer given to fv_train_step with the same batch /
+ * image_size.  The parity tests read z / scale / shift back to learn which LeakyReLU slope the GPU took
+ * for every element, so that the float64 oracle can be evaluated on the same side of each kink. */
+int fv_train_workspace_tensor(int batch, int image_size, int layer, int which, size_t* offset_bytes,
+                              int64_t* count);
+
 /* keras.optimizers.Adam(lr, beta_1, beta_2, decay) update (fd.py:376-379), Keras 2.2.4 formula:
  * t = iteration+1; lr_t = lr/(1+decay*iteration) * sqrt(1-b2^t)/(1-b1^t);
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m / (sqrt(v) + eps)  (eps = 1e-7). */
@@ -184,6 +193,36 @@ int64_t fv_bn_bwd_scratch_floats(int64_t rows, int C);
 int fv_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale, const float* shift,
               const float* mean, const float* invstd, int64_t rows, int C, float leaky, float* scratch,
               float* dbeta, float* dgamma, float* dz);
+/* ---- the fused forms fv_train_step actually runs (same Keras semantics, yd.py:212-215; exported so
+ * that each is checked against float64 on its own).  "Slots": [nslot][2][C] float64 accumulators the
+ * CALLER zeroes; producers ADD per-tile column sums with fp64 atomics (slot = tile % nslot), the
+ * consumer sums the slots in fixed order.  nslot = fv_bn_stat_slots(C); C % 4 == 0, C <= 1024 and C
+ * divides or is divided by 256. */
+int fv_bn_stat_slots(int C);
+/* conv forward storing the raw result z and ADDING the column sums of z and z^2 to `slots`. */
+int fv_conv2d_forward_slots(fv_ctx* ctx, const float* x, const float* w, int B, int H, int W, int cin, int cout,
+                            int ksize, int stride, float* z, double* slots, int nslot);
+/* training-mode BN + LeakyReLU (+ skip) fed by the slots: sums them, publishes mean / invstd / scale /
+ * shift, updates the moving statistics (may be NULL), writes out = leaky(z*scale+shift) (+ skip). */
+int fv_bn_act_slots(fv_ctx* ctx, const float* z, const double* slots, int nslot, int64_t rows, int C,
+                    const float* gamma, const float* beta, float eps, float momentum, float* mean, float* invstd,
+                    float* scale, float* shift, float* moving_mean, float* moving_var, const float* skip,
+                    float* out, float leaky);
+/* fv_conv2d_dgrad whose epilogue also reduces d-beta / d-gamma of the BN+LeakyReLU layer that PRODUCED
+ * the conv input: with that layer's pre-BN tensor bn_z [B][H][W][cin] and its mean / invstd / scale /
+ * shift, gy = dx * leaky'(bn_z*scale+shift) and the column sums of gy and gy*(bn_z-mean)*invstd are
+ * ADDED to `slots`.  cin % 4 == 0.  With scratch lent (fv_set_conv_scratch) the launch may take the
+ * tail split, whose fix-up kernel then does the same reduction. */
+int fv_conv2d_dgrad_bnred(fv_ctx* ctx, const float* dy, const float* w_t, int B, int H, int W, int cin,
+                          int cout_pad, int ksize, int stride, const float* addend, float* dx,
+                          const float* bn_z, const float* scale, const float* shift, const float* mean,
+                          const float* invstd, float leaky, double* slots, int nslot);
+/* backward of BN(train)+LeakyReLU through the slots.  reduced = 0: this call first adds the column
+ * sums to `slots` (its own reduction pass); reduced = 1: they are already there (fv_conv2d_dgrad_bnred).
+ * Then: d-beta, d-gamma = slot sums (as float), dz = scale*(gy - dbeta/rows - xhat*dgamma/rows). */
+int fv_bn_bwd_slots(fv_ctx* ctx, const float* g, const float* z, const float* scale, const float* shift,
+                    const float* mean, const float* invstd, int64_t rows, int C, float leaky, double* slots,
+                    int nslot, int reduced, float* dbeta, float* dgamma, float* dz);
 /* loss = mean((yp-yt)^2) over [rows][C]; dy [rows][c_pad] = 2(yp-yt)/(rows*C) zero padded;
  * dbias[C] = column sums of dy (may be NULL). */
 int fv_mse_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int c_pad,
@@ -193,6 +232,13 @@ int fv_mse_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int rows, in
  * dst: float32 [S][S][3]; geom (host, may be NULL) receives w_p, h_p, pad_t, pad_b, pad_l, pad_r.
  * Geometry is exact; pixels follow OpenCV's bicubic (a=-0.75) in fp32 (parity unpinned vs cv2). */
 int fv_letterbox(fv_ctx* ctx, const uint8_t* src, int h, int w, int image_size, float* dst, int32_t* geom);
+/* The same for a whole training batch in one launch (fd.py:98-147, the body of
+ * TrainingSequence.__getitem__): the n decoded images lie back to back in `packed` (device; one
+ * host-to-device copy per batch), image i at byte offsets[i] with hw[2i] rows and hw[2i+1] columns
+ * (offsets, hw, geom: HOST arrays; geom [n][6] may be NULL).  dst [n][S][S][3].  Pixels identical to
+ * n calls of fv_letterbox. */
+int fv_letterbox_batch(fv_ctx* ctx, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
+                       int image_size, float* dst, int32_t* geom);
 
 /* ------------------------------------------------------------------ secondary: three-scale YOLOv3
  * (SURVEY 8a-17/18).  The reference builds this graph in make_yolov3_model (yd.py:217-311) and

@@ -98,15 +98,22 @@ def _conv(x_nchw, w_ohwi, k, s):
     return F.conv2d(x_nchw, w, stride=s)
 
 
-def forward(params, state, x_nhwc, training, update_state=True, return_intermediates=False):
+def forward(params, state, x_nhwc, training, update_state=True, return_intermediates=False, positive=None):
     """x (B,S,S,3) -> (B,S/32,S/32,6).  training=True uses batch statistics and returns the new
-    moving state as second value; training=False uses `state` (Keras predict)."""
+    moving state as second value; training=False uses `state` (Keras predict).
+
+    positive: optional list (one bool NHWC tensor per base layer).  LeakyReLU's derivative jumps at 0, so
+    two correct evaluations in different precisions can sit on different sides of the kink for the few
+    elements within rounding of it -- and then their GRADIENTS differ by O(1) there.  With `positive`
+    given, element e of layer l takes slope 1 where positive[l][e] else 0.1, i.e. the function is
+    evaluated on the branch the device took (y -> y*slope is continuous across the kink, so the forward
+    value moves by less than the rounding that caused the disagreement)."""
     ents, _, _ = param_layout()
     x = x_nhwc.permute(0, 3, 1, 2)
     new_state = state.clone()
     skip = None
     inter = {}
-    for e in ents:
+    for li, e in enumerate(ents):
         k, s, cin, cout = e['k'], e['s'], e['cin'], e['cout']
         w = params[e['w_off']:e['w_off'] + cout * k * k * cin].view(cout, k, k, cin)
         if e['role'] == 'head':
@@ -132,7 +139,11 @@ def forward(params, state, x_nhwc, training, update_state=True, return_intermedi
             mean = state[e['mean_off']:e['mean_off'] + cout]
             var = state[e['var_off']:e['var_off'] + cout]
         y = (z - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + BN_EPS) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
-        x = F.leaky_relu(y, LEAKY)
+        if positive is None:
+            x = F.leaky_relu(y, LEAKY)
+        else:
+            pos = positive[li].permute(0, 3, 1, 2)
+            x = y * torch.where(pos, torch.ones((), dtype=y.dtype), torch.full((), LEAKY, dtype=y.dtype))
         if e['role'] == 'res_b':
             x = skip + x
         if return_intermediates:
@@ -159,10 +170,10 @@ def fd_loss(y_pred, y_true, eps=1e-7):
     return ((o_loss + l2_loss + c_loss) / 3.0).mean()
 
 
-def train_step_grads(params, state, x, y_true):
-    """One fwd + mse + bwd: -> (loss, grads flat, new_state)."""
+def train_step_grads(params, state, x, y_true, positive=None):
+    """One fwd + mse + bwd: -> (loss, grads flat, new_state).  positive: see forward()."""
     p = params.clone().requires_grad_(True)
-    y, new_state = forward(p, state, x, training=True)
+    y, new_state = forward(p, state, x, training=True, positive=positive)
     loss = mse(y, y_true)
     (g,) = torch.autograd.grad(loss, p)
     return loss.detach(), g, new_state

@@ -13,6 +13,9 @@ Outputs (data only -- inputs and expected outputs; no reference source text):
   tests/golden/gt_encoder.npz      TrainingSequence.__getitem__ GT tensors (fd.py:98-310)
   tests/golden/weight_reader.npz   WeightReader         (yd.py:67-124)
   tests/golden/decode_netout.npz   decode_netout/do_nms/correct_yolo_boxes (yd.py:335-444)
+  tests/golden/decode_netout_coco80.npz  the same on 80 classes and a small image (more int() boundary cases)
+  tests/golden/test_csv.npz        FaceDetector.test() csv rows: letterbox geometry, detect,
+                                   back-projection and str() formatting (fd.py:783-883)
 
 The reference does not exist on the GPU box; nothing at test time imports this file.
 Run:  python tests/golden/make_golden.py
@@ -387,9 +390,112 @@ def mint_decode_netout():
     print('decode_netout:', pre.shape, 'suppressed entries', int(((pre[:, 5:] != 0) & (post[:, 5:] == 0)).sum()))
 
 
+# --------------------------------------------------------------------------- test() csv rows (a-15)
+def mint_test_csv():
+    """Run the reference's FaceDetector.test() (fd.py:783-883) end to end on synthetic (h, w) shapes with
+    a chosen head output per image: imread / cv2 are shape-only stand-ins (pixels do not matter: the
+    fake predict ignores them), everything else -- pad computation, detect(), box back-projection with its
+    np.min/np.max clamps, the 60-row cap and the str() formatting of the rows -- is the reference's code."""
+    import contextlib
+    rng = np.random.default_rng(41)
+    hw = [(480, 640), (640, 480), (416, 416), (601, 1000), (1000, 601), (333, 777), (123, 124), (1080, 1920), (97, 31), (50, 400)]
+    files = ['t_%03d.jpg' % k for k in range(len(hw))]
+    sizes = dict(zip(files, hw))
+    heads = {f: synth_head(rng, 1, obj_sigma=2.0 + 0.3 * k) for k, f in enumerate(files)}
+    heads[files[2]][..., 0] = -9.0            # an image with no detections: no rows at all
+    heads[files[8]][..., 3:5] *= 4.0          # big boxes on the extreme portrait: clamps at w / h
+    heads[files[9]][..., 1:3] = rng.uniform(-0.3, 1.3, (1, 13, 13, 2))
+    seen = []
+
+    def imread(path):
+        seen.append(os.path.basename(path))
+        h, w = sizes[os.path.basename(path)]
+        return np.zeros((h, w, 3), np.uint8)
+
+    class CV:
+        INTER_CUBIC = 2
+        BORDER_CONSTANT = 0
+
+        @staticmethod
+        def resize(img, dsize, interpolation=None):
+            return np.zeros((dsize[1], dsize[0], 3), np.float64)
+
+        @staticmethod
+        def copyMakeBorder(img, t, b, l, r, mode, value=None):
+            return np.pad(img, ((t, b), (l, r), (0, 0)))
+
+    class Model:
+        def predict(self, x):
+            assert x.shape == (1, 416, 416, 3), x.shape      # the letterbox produced S x S
+            return heads[seen[-1]].copy()
+
+    fd.imread = imread
+    fd.cv = CV
+    with tempfile.TemporaryDirectory() as d:
+        for f in files:
+            open(os.path.join(d, f), 'w').close()
+        det = fd.FaceDetector.__new__(fd.FaceDetector)
+        det.conf = {'test_path': d, 'output_file_path': os.path.join(d, 'solution.csv')}
+        det.hps = {'face_conf_th': 0.5, 'nms_iou_th': 0.5, 'num_cands': 60}
+        det.nn_arch = {'image_size': 416}
+        det.cell_image_size = 416 // fd.FaceDetector.CELL_SIZE
+        det.model = Model()
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            det.test()
+        text = open(det.conf['output_file_path']).read()
+    rows = {f: [ln for ln in text.splitlines() if ln.split(',')[0] == f] for f in files}
+    assert sum(len(v) for v in rows.values()) == len(text.splitlines()) and not rows[files[2]]
+    np.savez_compressed(os.path.join(HERE, 'test_csv.npz'), files=np.array(files), hw=np.array(hw, np.int32),
+                        head=np.stack([heads[f][0] for f in files]),
+                        rows=np.array(['\n'.join(rows[f]) for f in files]), numpy_version=np.array(np.__version__))
+    print('test_csv:', len(files), 'images', [len(rows[f]) for f in files], 'rows; e.g.', rows[files[0]][0])
+
+
+def mint_decode_netout_coco80():
+    """Second decode_netout fixture: 80 classes (the COCO demo's real width) and a SMALL image, where the
+    int() truncation of correct_yolo_boxes lands on many more integer boundaries.  The head outputs are a
+    quiet background (objectness logit -12: below any threshold) plus a few hundred "hot" cells, stored
+    sparsely (cell index + 255 values) to keep the fixture small.  Pairs whose corrected boxes have zero
+    area would raise ZeroDivisionError in bbox_iou (yd.py:194, python ints): checked that none collapses."""
+    rng = np.random.default_rng(57)
+    anchors = [[116, 90, 156, 198, 373, 326], [30, 61, 62, 45, 59, 119], [10, 13, 16, 30, 33, 23]]
+    ncls = 80
+    net_h = net_w = 416
+    image_h, image_w = 375, 500
+    sparse = {}
+    boxes = []
+    for s, (g, nhot) in enumerate(((13, 60), (26, 110), (52, 160))):
+        no = np.zeros((g, g, 3 * (5 + ncls)), np.float32)
+        no.reshape(g, g, 3, -1)[..., 4] = -12.0
+        # hot cells in clusters (neighbouring cells with boxes larger than a cell overlap -> suppression)
+        centres = rng.integers(1, g - 1, (nhot // 5, 2))
+        cells = np.unique(np.clip(np.repeat(centres, 5, 0) + rng.integers(-1, 2, (nhot // 5 * 5, 2)), 0, g - 1), axis=0)
+        vals = rng.normal(0, 1.0, (len(cells), 3, 5 + ncls)).astype(np.float32)
+        vals[..., 4] += 1.0; vals[..., 2:4] = vals[..., 2:4] * 0.25 + 0.5
+        vals[..., 5:] -= 2.0
+        fav = rng.integers(0, ncls, len(cells))                      # clusters agree on a few classes
+        for k in range(len(cells)):
+            vals[k, :, 5 + fav[k] % 7] += 4.0
+        vals = vals.reshape(len(cells), -1)
+        no[cells[:, 0], cells[:, 1]] = vals
+        sparse['cells_%d' % s] = cells.astype(np.int32); sparse['vals_%d' % s] = vals
+        boxes += yd.decode_netout(no.copy(), anchors[s], s, 0.5, net_h, net_w)
+    pre = np.array([[b.xmin, b.ymin, b.xmax, b.ymax, b.objness] + list(b.classes) for b in boxes], np.float64)
+    yd.correct_yolo_boxes(boxes, image_h, image_w, net_h, net_w)
+    assert all(b.xmax > b.xmin and b.ymax > b.ymin for b in boxes), 'zero-area box: redraw'
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        yd.do_nms(boxes, 0.5)
+    post = np.array([[b.xmin, b.ymin, b.xmax, b.ymax, b.objness] + list(b.classes) for b in boxes], np.float64)
+    np.savez_compressed(os.path.join(HERE, 'decode_netout_coco80.npz'), pre=pre, post=post,
+                        anchors=np.array(anchors, np.int32), image_hw=np.array([image_h, image_w], np.int32),
+                        background_obj=np.float32(-12.0), **sparse)
+    print('decode_netout_coco80:', pre.shape, 'suppressed entries', int(((pre[:, 5:] != 0) & (post[:, 5:] == 0)).sum()))
+
+
 if __name__ == '__main__':
-    mint_detect()
-    mint_iou()
-    mint_gt()
-    mint_weight_reader()
-    mint_decode_netout()
+    which = sys.argv[1:] or ['detect', 'iou', 'gt', 'weight_reader', 'decode_netout', 'test_csv', 'decode_netout_coco80']
+    for name in which:
+        {'detect': mint_detect, 'iou': mint_iou, 'gt': mint_gt, 'weight_reader': mint_weight_reader,
+         'decode_netout': mint_decode_netout, 'test_csv': mint_test_csv, 'decode_netout_coco80': mint_decode_netout_coco80}[name]()

@@ -113,3 +113,50 @@ def test_main_reads_json_from_cwd(tmp_path, monkeypatch):
     json.dump({'fd_conf': conf, 'fi_conf': {}}, open('face_vijnana_yolov3.json', 'w'))
     face_detection.main()
     assert os.path.exists(conf['output_file_path'])
+
+
+def test_csv_rows_match_the_reference_test_golden(tmp_path, monkeypatch, golden_dir):
+    """a-15: the rows FaceDetector.test() writes -- letterbox geometry, detect(), the back-projection with its
+    np.min/np.max clamps (fd.py:841-851), the 60-row cap and the str() formatting (fd.py:866-873) -- against
+    tests/golden/test_csv.npz, minted by running the reference's own test() on the same (h, w) shapes with
+    the same head output per image (make_golden.py: imread/cv2 are shape-only stand-ins there, here the
+    network is replaced by the golden head the same way).  Text-identical rows, per file."""
+    import torch
+    from face_vijnana_yolov3_amd import data
+    from face_vijnana_yolov3_amd.face_detection import FaceDetector
+    g = np.load(os.path.join(golden_dir, 'test_csv.npz'))
+    assert str(g['numpy_version']).split('.')[0] == np.__version__.split('.')[0]     # str(np.float64) formatting era
+    files = [str(f) for f in g['files']]
+    hw = {f: tuple(int(v) for v in g['hw'][k]) for k, f in enumerate(files)}
+    monkeypatch.chdir(tmp_path)
+    root = str(tmp_path / 'imgs'); os.makedirs(root)
+    for f in files:
+        open(os.path.join(root, f), 'w').close()
+    conf = _conf(root, 'test')
+    fd = FaceDetector(conf)
+    current = []
+
+    def loader(path):
+        current.append(os.path.basename(path))
+        h, w = hw[current[-1]]
+        return np.zeros((h, w, 3), np.uint8)
+
+    def predict_device(x):
+        assert tuple(x.shape) == (1, 416, 416, 3)
+        return torch.from_numpy(g['head'][files.index(current[-1])][None]).cuda()
+
+    monkeypatch.setattr(data, '_pil_loader', loader)
+    monkeypatch.setattr(fd.model, 'predict_device', predict_device)
+    fd.test()
+    text = open(conf['output_file_path']).read().splitlines()
+    for k, f in enumerate(files):
+        want = str(g['rows'][k]).split('\n') if str(g['rows'][k]) else []
+        got = [ln for ln in text if ln.split(',')[0] == f]
+        assert got == want, (f, got[:2], want[:2])
+    assert sum(len(str(r).split('\n')) for r in g['rows'] if str(r)) == len(text)
+    # evaluate() writes the same rows (same code path in the reference, fd.py:700-738)
+    import pandas as pd
+    pd.DataFrame([[0, files[0], 1, 10.0, 10.0, 20.0, 20.0]], columns=data.CSV_COLUMNS).to_csv(os.path.join(root, 'validation.csv'), index=False)
+    fd.conf = dict(conf, output_file_path=os.path.join(root, 'solution_eval.csv'))
+    fd.evaluate()
+    assert open(os.path.join(root, 'solution_eval.csv')).read().splitlines() == text

@@ -1,0 +1,219 @@
+"""Operator-level GPU parity of the FUSED forms fv_train_step runs (they used to be reachable only through
+the whole step): conv forward -> fp64 accumulator slots -> bn_act_stats; data-gradient with the fused
+BatchNorm-backward reduction (FV_EPI_BNRED: stride 1, stride-2 four-class launches, residual addend, and
+the tail-split fix-up variant) -> bn_bwd_apply_slots.  Reference: float64 torch-CPU restatement of the
+same Keras ops (yolov3_detect.py:212-215 BatchNormalization(eps 1e-3) + LeakyReLU(0.1); their gradients).
+
+Tolerances are a few fp32 ulps of the absolute-value sums (the `_check` bound of test_ops_gpu.py).  The
+LeakyReLU mask of an element is decided by the sign of fl(fl(z*scale)+shift) -- the library is built with
+-ffp-contract=off, so torch's float32 `z*scale+shift` reproduces that decision bit for bit and no element
+has to be excluded around the kink."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+LEAKY = 0.1
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from face_vijnana_yolov3_amd._lib import Context
+    return Context(0)
+
+
+def _rand(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g, dtype=torch.float64) * (hi - lo) + lo).float()
+
+
+def _ref_conv(x, w, k, s):
+    xn = x.permute(0, 3, 1, 2)
+    if k == 3:
+        xn = F.pad(xn, (1, 1, 1, 1))
+    return F.conv2d(xn, w.permute(0, 3, 1, 2), stride=s).permute(0, 2, 3, 1).contiguous()
+
+
+def _dgrad_ref(dy, w, B, H, cin, k, s):
+    """float64 data-gradient and its absolute-value bound."""
+    x = torch.zeros((B, H, H, cin), dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(_ref_conv(x, w.double(), k, s), x, dy.double())
+    xa = torch.zeros((B, H, H, cin), dtype=torch.float64, requires_grad=True)
+    (bound,) = torch.autograd.grad(_ref_conv(xa, w.double().abs(), k, s), xa, dy.double().abs())
+    return ref, bound
+
+
+def _bn_vectors(C, seed):
+    """Arbitrary (not mutually consistent) per-channel vectors: the kernels take them as inputs."""
+    return (_rand((C,), seed, 0.5, 1.5), _rand((C,), seed + 1, -0.5, 0.5), _rand((C,), seed + 2, -0.3, 0.3), _rand((C,), seed + 3, 0.5, 2.0))
+
+
+def _mask(z, scale, shift):
+    """The kernels' slope decision, bit for bit: fl(fl(z*scale)+shift) > 0 in float32."""
+    pre = z * scale + shift
+    return torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, LEAKY)).double()
+
+
+BNRED_CASES = [
+    # B, H, cin, cout, k, s, cpad, addend
+    (2, 16, 64, 128, 3, 1, 128, False),     # 64-wide tiles
+    (2, 16, 128, 256, 3, 1, 256, True),     # 128-wide tiles + residual addend
+    (2, 16, 32, 64, 3, 2, 64, False),       # stride 2: four parity classes, 32-wide tiles
+    (3, 12, 128, 128, 3, 2, 128, False),    # stride 2, 128-wide tiles, M = 108 per class (tail rows)
+    (2, 13, 256, 128, 1, 1, 128, True),     # 1x1, odd pixel count
+    (2, 13, 1024, 6, 3, 1, 32, False),      # the head's data-gradient (dy padded to 32 channels) -> conv_73's BN
+]
+
+
+def _run_bnred(ctx, B, H, cin, cout, k, s, cpad, with_add, seed=100):
+    from face_vijnana_yolov3_amd import ops
+    Ho = H // s
+    w = _rand((cout, k, k, cin), seed, -0.3, 0.3)
+    dy = torch.zeros((B, Ho, Ho, cpad)); dy[..., :cout] = _rand((B, Ho, Ho, cout), seed + 1)
+    add = _rand((B, H, H, cin), seed + 2) if with_add else None
+    z = _rand((B, H, H, cin), seed + 3, -2.0, 2.0)
+    scale, shift, mean, invstd = _bn_vectors(cin, seed + 4)
+    slots = ops.stat_slots(cin, 'cuda')
+    dx = ops.conv2d_dgrad_bnred(ctx, dy.cuda(), w.cuda(), (H, H), s, z.cuda(), scale.cuda(), shift.cuda(), mean.cuda(), invstd.cuda(),
+                                slots, addend=None if add is None else add.cuda())
+    ref, bound = _dgrad_ref(dy[..., :cout], w, B, H, cin, k, s)
+    if add is not None:
+        ref = ref + add.double(); bound = bound + add.double().abs()
+    return dx, slots, ref, bound, z, (scale, shift, mean, invstd)
+
+
+@pytest.mark.parametrize('B,H,cin,cout,k,s,cpad,with_add', BNRED_CASES)
+def test_dgrad_with_fused_bn_backward_reduction(ctx, B, H, cin, cout, k, s, cpad, with_add):
+    dx, slots, ref, bound, z, (scale, shift, mean, invstd) = _run_bnred(ctx, B, H, cin, cout, k, s, cpad, with_add)
+    err = (dx.double().cpu() - ref).abs()
+    assert (err <= 2e-6 * bound + 1e-6).all(), 'dgrad: max err %.3e' % err.max().item()
+    m = _mask(z, scale, shift)
+    xhat = ((z - mean) * invstd).double()          # the kernel's float32 xhat, exactly
+    rows = ref.numel() // cin
+    gy = (ref * m).view(rows, cin)
+    s_ = slots.sum(0).cpu()                        # [2][C] float64
+    for name, got, want, mag in (('d-beta', s_[0], gy.sum(0), (bound * m).view(rows, cin).sum(0)),
+                                 ('d-gamma', s_[1], (gy * xhat.view(rows, cin)).sum(0), (bound * m * xhat.abs()).view(rows, cin).sum(0))):
+        e = (got - want).abs()
+        tol = 1e-5 * mag + 1e-6
+        assert (e <= tol).all(), '%s: max err %.3e (tol there %.3e, |want| max %.3e)' % (name, e.max().item(), tol[e.argmax()].item(), want.abs().max().item())
+    # every tile landed in some slot and nothing else was touched
+    assert torch.isfinite(slots).all()
+
+
+def test_dgrad_bnred_through_the_tail_split_fixup(ctx):
+    """307 output tiles x 72 K steps: with scratch lent the launcher cuts the tail tiles into K slices and
+    conv_tail_fixup_kernel performs the epilogue -- including the fused BN-backward reduction."""
+    from face_vijnana_yolov3_amd import ops
+    B, H, cin, cout, k, s = 2, 140, 128, 256, 3, 1
+    plain = _run_bnred(ctx, B, H, cin, cout, k, s, cout, True, seed=300)
+    ctx.set_conv_scratch(torch.empty(64 << 20, dtype=torch.uint8, device='cuda'))
+    try:
+        split = _run_bnred(ctx, B, H, cin, cout, k, s, cout, True, seed=300)
+    finally:
+        ctx.set_conv_scratch(None)
+    assert not torch.equal(plain[0], split[0])      # the split really ran (other fp32 summation order)
+    for dx, slots, ref, bound, z, (scale, shift, mean, invstd) in (plain, split):
+        err = (dx.double().cpu() - ref).abs()
+        assert (err <= 2e-6 * bound + 1e-6).all(), err.max().item()
+        m = _mask(z, scale, shift); xhat = ((z - mean) * invstd).double()
+        rows = ref.numel() // cin
+        gy = (ref * m).view(rows, cin)
+        s_ = slots.sum(0).cpu()
+        assert ((s_[0] - gy.sum(0)).abs() <= 1e-5 * (bound * m).view(rows, cin).sum(0) + 1e-6).all()
+        assert ((s_[1] - (gy * xhat.view(rows, cin)).sum(0)).abs() <= 1e-5 * (bound * m * xhat.abs()).view(rows, cin).sum(0) + 1e-6).all()
+
+
+@pytest.mark.parametrize('rows,C,reduced', [(1000, 32, False), (4097, 64, False), (338, 1024, False), (70000, 128, False),
+                                            (6760, 512, True), (27040, 256, True)])
+def test_bn_backward_apply_from_slots(ctx, rows, C, reduced):
+    """bn_bwd_apply_slots_kernel: dz, d-beta, d-gamma from the slots -- filled by the kernel's own reduction
+    pass (reduced=False) or beforehand, the way the data-gradient epilogue leaves them (reduced=True: exact
+    per-128-row column sums spread over the slots)."""
+    from face_vijnana_yolov3_amd import ops
+    z = _rand((rows, C), 41, -2.0, 2.0); g = _rand((rows, C), 42)
+    scale, shift, mean, invstd = _bn_vectors(C, 43)
+    m = _mask(z, scale, shift); xhat = ((z - mean) * invstd).double()
+    gy = g.double() * m
+    slots = ops.stat_slots(C, 'cuda')
+    if reduced:
+        ns = slots.shape[0]
+        nt = (rows + 127) // 128
+        pad = torch.zeros((nt * 128, C), dtype=torch.float64)
+        a = pad.clone(); a[:rows] = gy; b = pad.clone(); b[:rows] = gy * xhat
+        a = a.view(nt, 128, C).sum(1); b = b.view(nt, 128, C).sum(1)
+        host = torch.zeros((ns, 2, C), dtype=torch.float64)
+        for t in range(nt):
+            host[t % ns, 0] += a[t]; host[t % ns, 1] += b[t]
+        slots.copy_(host)
+    dz, dgamma, dbeta = ops.bn_bwd_slots(ctx, g.cuda(), z.cuda(), scale.cuda(), shift.cuda(), mean.cuda(), invstd.cuda(), slots, reduced)
+    rdb, rdg = gy.sum(0), (gy * xhat).sum(0)
+    mag_b, mag_g = gy.abs().sum(0), (gy * xhat).abs().sum(0)
+    assert ((dbeta.cpu().double() - rdb).abs() <= 1e-5 * mag_b + 1e-6).all()
+    assert ((dgamma.cpu().double() - rdg).abs() <= 1e-5 * mag_g + 1e-6).all()
+    # dz from the kernel's own (float) d-beta / d-gamma: isolates the apply arithmetic
+    db, dg = dbeta.cpu().double(), dgamma.cpu().double()
+    rdz = scale.double() * (gy - db / rows - xhat * (dg / rows))
+    mag = scale.double().abs() * (gy.abs() + db.abs() / rows + xhat.abs() * dg.abs() / rows)
+    err = (dz.cpu().double() - rdz).abs()
+    assert (err <= 1e-6 * mag + 1e-7).all(), err.max().item()
+    # and the textbook gradient (autograd through batch statistics) when the vectors ARE the batch statistics
+    if not reduced:
+        zt = z.double().clone().requires_grad_(True)
+        gam = _rand((C,), 47, 0.5, 1.5).double().requires_grad_(True); bet = _rand((C,), 48).double().requires_grad_(True)
+        mu = zt.mean(0); var = zt.var(0, unbiased=False)
+        y = (zt - mu) / torch.sqrt(var + 1e-3) * gam + bet
+        act = F.leaky_relu(y, LEAKY)
+        adz, adg, adb = torch.autograd.grad(act, (zt, gam, bet), g.double())
+        is32 = (1.0 / torch.sqrt(var.detach() + 1e-3)).float(); mu32 = mu.detach().float()
+        sc32 = gam.detach().float() * is32; sh32 = bet.detach().float() - mu32 * sc32
+        slots.zero_()
+        dz2, dg2, db2 = ops.bn_bwd_slots(ctx, g.cuda(), z.cuda(), sc32.cuda(), sh32.cuda(), mu32.cuda(), is32.cuda(), slots, False)
+        near = (y.detach().abs() < 1e-5)            # float32 statistics vs float64 ones can disagree about the slope there
+        sc = math.sqrt(rows)
+        torch.testing.assert_close(db2.cpu().double(), adb, rtol=1e-4, atol=1e-5 * sc)
+        torch.testing.assert_close(dg2.cpu().double(), adg, rtol=1e-4, atol=1e-5 * sc)
+        e2 = (dz2.cpu().double() - adz).abs()
+        assert (e2[~near] <= 2e-5 + 1e-4 * adz[~near].abs()).all(), e2[~near].max().item()
+
+
+@pytest.mark.parametrize('B,H,cin,cout,k,s,with_skip', [(2, 16, 32, 64, 3, 2, False), (3, 13, 64, 128, 3, 1, True), (1, 26, 256, 128, 1, 1, False),
+                                                         (2, 12, 3, 32, 3, 1, False), (4, 13, 512, 1024, 3, 1, True)])
+def test_conv_slots_then_bn_act(ctx, B, H, cin, cout, k, s, with_skip):
+    """conv forward adding its column sums to the slots, then bn_act_stats_kernel: statistics, moving
+    statistics (Keras: var * n/(n-(1+eps)), momentum 0.99), scale/shift and the activated output."""
+    from face_vijnana_yolov3_amd import ops
+    x = _rand((B, H, H, cin), 51); w = _rand((cout, k, k, cin), 52, -0.2, 0.2)
+    gamma = _rand((cout,), 53, 0.5, 1.5); beta = _rand((cout,), 54)
+    mm = _rand((cout,), 55); mv = _rand((cout,), 56, 0.5, 2.0)
+    Ho = H // s
+    skip = _rand((B, Ho, Ho, cout), 57) if with_skip else None
+    slots = ops.stat_slots(cout, 'cuda')
+    z = ops.conv2d_forward_slots(ctx, x.cuda(), w.cuda(), s, slots)
+    ref = _ref_conv(x.double(), w.double(), k, s); bound = _ref_conv(x.double().abs(), w.double().abs(), k, s)
+    assert ((z.double().cpu() - ref).abs() <= 2e-6 * bound + 1e-6).all()
+    rows = ref.numel() // cout
+    zc = z.cpu().double().view(rows, cout)
+    s_ = slots.sum(0).cpu()
+    # column sums of the kernel's own z: fp32 per-tile partials, fp64 across tiles
+    assert ((s_[0] - zc.sum(0)).abs() <= 1e-5 * zc.abs().sum(0) + 1e-6).all()
+    assert ((s_[1] - (zc * zc).sum(0)).abs() <= 1e-5 * (zc * zc).sum(0) + 1e-6).all()
+    mmd, mvd = mm.cuda(), mv.cuda()
+    out, mean, invstd, scale, shift = ops.bn_act_slots(ctx, z, slots, gamma.cuda(), beta.cuda(), 1e-3, 0.99, mmd, mvd,
+                                                       None if skip is None else skip.cuda())
+    rmean = zc.mean(0); rvar = zc.var(0, unbiased=False)
+    torch.testing.assert_close(mean.cpu().double(), rmean, rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(invstd.cpu().double(), 1 / torch.sqrt(rvar + 1e-3), rtol=2e-5, atol=0)
+    torch.testing.assert_close(mmd.cpu().double(), 0.99 * mm.double() + 0.01 * rmean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(mvd.cpu().double(), 0.99 * mv.double() + 0.01 * rvar * rows / (rows - 1.001), rtol=1e-5, atol=1e-6)
+    # activation from the kernel's own published scale / shift: exact arithmetic check
+    sc, sh = scale.cpu(), shift.cpu()
+    torch.testing.assert_close(sc.double(), gamma.double() * invstd.cpu().double(), rtol=1e-6, atol=0)
+    pre = z.cpu().view(rows, cout) * sc + sh
+    want = torch.where(pre > 0, pre, pre * LEAKY)
+    if skip is not None:
+        want = want + skip.view(rows, cout)
+    assert torch.equal(out.cpu().view(rows, cout), want)

@@ -139,6 +139,62 @@ def test_train_step_matches_oracle(eng):
     assert eng.iterations == 2
 
 
+def _tight_step_check(eng, seed, B, S, report):
+    """One train step against the float64 oracle EVALUATED ON THE DEVICE'S SIDE OF EVERY LeakyReLU KINK
+    (oracle forward(positive=...), slopes read back through fv_train_workspace_tensor).  With the branch
+    fixed the step is a smooth function, so every gradient tensor must agree to fp32 rounding: relative L2
+    per tensor <= max(6 x the float32 oracle's own error on the same branch, 2e-5) -- three orders of
+    magnitude below the 2e-2 floor the plain comparison needs."""
+    from oracle import net_oracle as no
+    p64, s64, x, yt = _setup(seed, B, S)
+    eng.set_params(p64.float(), s64.float())
+    eng.iterations = 0
+    eng.m = eng.v = eng.grads = None
+    loss = eng.forward_backward(x.float(), yt.float())
+    torch.cuda.synchronize()
+    pos = [m.cpu() for m in eng.leaky_slopes_taken(B, S)]
+    l64, g64, ns64 = no.train_step_grads(p64, s64, x, yt, positive=pos)
+    l32, g32, ns32 = no.train_step_grads(p64.float(), s64.float(), x.float(), yt.float(), positive=pos)
+    assert abs(loss.item() - l64.item()) <= 4 * abs(l32.item() - l64.item()) + 1e-6 * abs(l64.item())
+    _within(eng.state.cpu(), ns64, ns32, 'bn moving state')
+    ents, _, _ = no.param_layout()
+    g = eng.grads.cpu()
+    worst = {}
+    for e in ents:
+        k, cin, cout = e['k'], e['cin'], e['cout']
+        parts = [('dW', slice(e['w_off'], e['w_off'] + cout * k * k * cin))]
+        if e['has_bn']:
+            parts += [('dgamma', slice(e['gamma_off'], e['gamma_off'] + cout)), ('dbeta', slice(e['beta_off'], e['beta_off'] + cout))]
+        else:
+            parts += [('dbias', slice(e['bias_off'], e['bias_off'] + 6))]
+        for nm, sl in parts:
+            rel = _grad_close(g[sl], g64[sl], g32[sl], '%s %s' % (nm, e['name']), factor=6.0, floor=2e-5)
+            worst[nm] = max(worst.get(nm, 0.0), rel)
+    # the top of the network additionally element by element (conv_73 / conv_72 and the head)
+    for e in ents[-3:]:
+        k, cin, cout = e['k'], e['cin'], e['cout']
+        sl = slice(e['w_off'], e['w_off'] + cout * k * k * cin)
+        _within(g[sl], g64[sl], g32[sl], 'dW ' + e['name'], factor=6.0, floor=2e-6)
+        if e['has_bn']:
+            for nm in ('gamma_off', 'beta_off'):
+                sl = slice(e[nm], e[nm] + cout)
+                _within(g[sl], g64[sl], g32[sl], nm + ' ' + e['name'], factor=6.0, floor=2e-6)
+    report.append('B=%d S=%d worst rel-L2 on the device branch: %s' % (B, S, ', '.join('%s %.2e' % kv for kv in sorted(worst.items()))))
+    print(report[-1])
+
+
+def test_train_step_is_tight_on_the_device_branch(eng):
+    rep = []
+    _tight_step_check(eng, 9, 4, 96, rep)
+    _tight_step_check(eng, 10, 6, 128, rep)     # tail-split tile counts in the training forward
+
+
+def test_train_step_416_batch2_is_tight_on_the_device_branch(eng):
+    """BASELINE image size (real tile counts per layer, stride-2 four-class data-gradients at 208..13)."""
+    rep = []
+    _tight_step_check(eng, 23, 2, 416, rep)
+
+
 def test_workspace_too_small_is_reported(eng):
     import ctypes
     from face_vijnana_yolov3_amd._lib import lib, ptr

@@ -89,3 +89,29 @@ def test_gradient_finite_difference():
         lm = no.mse(no.forward(pm, st, x, True, update_state=False)[0], yt).item()
         fd = (lp - lm) / (2 * h)
         assert math.isclose(fd, g[i].item(), rel_tol=1e-3, abs_tol=1e-7), (i, fd, g[i].item())
+
+
+def test_forced_slopes_equal_plain_leaky_when_they_are_its_own():
+    """forward(positive=...): with the oracle's own sign pattern it IS the plain LeakyReLU network (values,
+    BN state and gradients identical); flipping one element changes the gradient of its layer's d-beta."""
+    p, st = no.init_params(5, torch.float64)
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(2, 64, 64, 3, dtype=torch.float64, generator=g); yt = torch.rand(2, 2, 2, 6, dtype=torch.float64, generator=g)
+    _, _, inter = no.forward(p, st, x, training=True, return_intermediates=True)
+    ents, _, _ = no.param_layout()
+    pos = []
+    skip = None
+    for e in ents[:-1]:   # recover the pre-activation sign from (z, batch statistics)
+        z = inter[e['name']][0]
+        c = e['cout']
+        mean = z.mean(dim=(0, 1, 2)); var = ((z - mean) ** 2).mean(dim=(0, 1, 2))
+        y = (z - mean) / torch.sqrt(var + no.BN_EPS) * p[e['gamma_off']:e['gamma_off'] + c] + p[e['beta_off']:e['beta_off'] + c]
+        pos.append(y > 0)
+    l0, g0, s0 = no.train_step_grads(p, st, x, yt)
+    l1, g1, s1 = no.train_step_grads(p, st, x, yt, positive=pos)
+    assert torch.equal(s0, s1) and abs(l0.item() - l1.item()) <= 1e-15 * abs(l0.item())
+    torch.testing.assert_close(g0, g1, rtol=1e-12, atol=1e-18)
+    pos[51] = pos[51].clone(); pos[51][0, 0, 0, 0] = ~pos[51][0, 0, 0, 0]
+    _, g2, _ = no.train_step_grads(p, st, x, yt, positive=pos)
+    e = ents[51]
+    assert g2[e['beta_off']].item() != g0[e['beta_off']].item()

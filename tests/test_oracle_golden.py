@@ -85,11 +85,25 @@ def test_weight_reader_matches_reference(golden_dir):
                 np.testing.assert_array_equal(a, g['%s_%s_%d' % (tag, name, k)], err_msg=name)
 
 
-def test_decode_netout_and_nms_secondary(golden_dir):
-    g = _load(golden_dir, 'decode_netout.npz')
+def coco80_netouts(g):
+    """Rebuild the dense head outputs of decode_netout_coco80.npz from its sparse form."""
+    outs = []
+    for s, gsz in enumerate((13, 26, 52)):
+        no = np.zeros((gsz, gsz, g['vals_%d' % s].shape[1]), np.float32)
+        no.reshape(gsz, gsz, 3, -1)[..., 4] = g['background_obj']
+        c = g['cells_%d' % s]
+        no[c[:, 0], c[:, 1]] = g['vals_%d' % s]
+        outs.append(no)
+    return outs
+
+
+@pytest.mark.parametrize('fixture', ['decode_netout.npz', 'decode_netout_coco80.npz'])
+def test_decode_netout_and_nms_secondary(golden_dir, fixture):
+    g = _load(golden_dir, fixture)
+    netouts = coco80_netouts(g) if 'coco80' in fixture else [g['netout_%d' % s] for s in range(3)]
     rows = []
     for s in range(3):
-        rows += host_oracle.decode_netout(g['netout_%d' % s], list(g['anchors'][s]), s, 0.5, 416, 416)
+        rows += host_oracle.decode_netout(netouts[s], list(g['anchors'][s]), s, 0.5, 416, 416)
     pre = np.array(rows, np.float64)
     assert pre.shape == g['pre'].shape
     np.testing.assert_allclose(pre, g['pre'], rtol=1e-6, atol=1e-7)

@@ -113,9 +113,10 @@ def test_invalid_arguments_report_errors(ctx):
 
 
 @pytest.mark.parametrize('h,w,S', [(37, 61, 64), (80, 45, 64), (64, 64, 64), (480, 640, 416), (601, 333, 416), (1080, 1920, 416)])
-def test_device_letterbox(ctx, h, w, S):
-    """fv_letterbox: geometry exact; pixels within fp32 rounding of the float64 statement of the same
-    bicubic formula (cv2 itself is absent: parity unpinned)."""
+def test_device_letterbox_pixels_parity_unpinned(ctx, h, w, S):
+    """fv_letterbox: geometry exact (pinned by the GT-encoder golden); pixels within fp32 rounding of the
+    float64 statement of the same bicubic formula by the same author -- PARITY UNPINNED against
+    cv2.resize(INTER_CUBIC) itself, which is absent from this image."""
     from face_vijnana_yolov3_amd import data
     from face_vijnana_yolov3_amd.postproc import letterbox_device
     rng = np.random.default_rng(h * 1000 + w)
@@ -127,3 +128,22 @@ def test_device_letterbox(ctx, h, w, S):
     w_p, h_p, pt, pb, pl, pr = data.letterbox_geometry(h, w, S)
     o = out.cpu().numpy()
     assert o[:pt].sum() == 0 and o[S - pb:].sum() == 0 and o[:, :pl].sum() == 0 and o[:, S - pr:].sum() == 0
+
+
+def test_letterbox_batch_equals_single_launches(ctx):
+    """fv_letterbox_batch (one launch per training batch, images packed back to back in one buffer):
+    bit-identical pixels and the same geometry as one fv_letterbox call per image."""
+    import torch
+    from face_vijnana_yolov3_amd.postproc import letterbox_batch_device, letterbox_device, pack_images
+    rng = np.random.default_rng(5)
+    shapes = [(37, 61), (80, 45), (64, 64), (480, 640), (601, 333), (300, 1100), (1080, 1920)] * 10   # 70 images: two launches
+    raws = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    out, geoms = letterbox_batch_device(ctx, raws, 416, torch.device('cuda', 0))
+    assert tuple(out.shape) == (70, 416, 416, 3)
+    for i in (0, 1, 2, 3, 4, 5, 6, 63, 64, 69):
+        one, g1 = letterbox_device(ctx, raws[i], 416)
+        assert tuple(g1) == tuple(geoms[i])
+        assert torch.equal(out[i], one), i
+    packed = pack_images(raws[:3])
+    out2, _ = letterbox_batch_device(ctx, None, 416, torch.device('cuda', 0), packed=packed)
+    assert torch.equal(out2, out[:3])

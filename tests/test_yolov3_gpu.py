@@ -69,26 +69,71 @@ def test_darknet_full_weights_roundtrip(model, tmp_path):
     assert np.array_equal(model.params.cpu().numpy(), p) and np.array_equal(model.state.cpu().numpy(), s)
 
 
-def test_decode_nms_matches_reference_golden(model, golden_dir):
+def _coco80_netouts(g):
+    outs = []
+    for s, gsz in enumerate((13, 26, 52)):
+        no = np.zeros((gsz, gsz, g['vals_%d' % s].shape[1]), np.float32)
+        no.reshape(gsz, gsz, 3, -1)[..., 4] = g['background_obj']
+        c = g['cells_%d' % s]
+        no[c[:, 0], c[:, 1]] = g['vals_%d' % s]
+        outs.append(no)
+    return outs
+
+
+@pytest.mark.parametrize('fixture', ['decode_netout.npz', 'decode_netout_coco80.npz'])
+def test_decode_nms_matches_reference_golden(model, golden_dir, fixture):
+    """fv_yolo_decode_nms against vectors minted by the reference's decode_netout / correct_yolo_boxes /
+    do_nms (4 classes on a 1440x1920 image; 80 classes on a 375x500 image).  Candidate set, order and
+    objectness: exact.  Integer corners: exact, except where the reference's own pre-truncation value --
+    recomputed here from the golden's float corners -- sits within a few float32 ulps of an integer: the
+    kernel's exp is the correctly rounded one, NumPy's SIMD float32 exp may differ by 1 ulp, and int()
+    turns that into a whole pixel exactly there and nowhere else.  Suppression pattern: exactly what the
+    reference's greedy per-class NMS (restated in oracle/host_oracle.py and pinned by the same golden)
+    gives on the DEVICE's integer boxes -- so a corner that moved is the only way it can differ."""
     from face_vijnana_yolov3_amd.yolov3 import decode_nms
-    g = np.load(os.path.join(golden_dir, 'decode_netout.npz'))
-    ys = [torch.from_numpy(g['netout_%d' % s]).cuda() for s in range(3)]
+    from oracle import host_oracle
+    g = np.load(os.path.join(golden_dir, fixture))
+    netouts = _coco80_netouts(g) if 'coco80' in fixture else [g['netout_%d' % s] for s in range(3)]
+    ys = [torch.from_numpy(a).cuda() for a in netouts]
     ih, iw = [int(v) for v in g['image_hw']]
     res = decode_nms(model.ctx, ys[0], ys[1], ys[2], (ih, iw), (416, 416), g['anchors'].tolist(), 0.5, 0.5)
-    post = g['post']
+    pre, post = g['pre'], g['post']
     n = post.shape[0]
     assert res['boxes'].shape[0] == n                                   # same candidates, same order
     np.testing.assert_allclose(res['objness'].cpu().numpy(), post[:, 4], rtol=3e-7, atol=0)
-    # integer corners: float32 chain with a 1-ulp different exp may flip an int() truncation
-    d = np.abs(res['boxes'].cpu().numpy().astype(np.int64) - post[:, :4].astype(np.int64))
-    assert d.max() <= 1 and (d == 0).mean() >= 0.995, (d.max(), (d == 0).mean())
+    got = res['boxes'].cpu().numpy().astype(np.int64)
+    want = post[:, :4].astype(np.int64)
+    # the reference's pre-truncation values (yd.py:389-404), float32 like its np.float32 corners
+    if (416.0 / iw) < (416.0 / ih):
+        new_w, new_h = 416.0, (ih * 416.0) / iw
+    else:
+        new_h, new_w = 416.0, (iw * 416.0) / ih
+    x_off, x_sc = (416 - new_w) / 2. / 416, new_w / 416
+    y_off, y_sc = (416 - new_h) / 2. / 416, new_h / 416
+    f = pre[:, :4].astype(np.float32)
+    v = np.stack([(f[:, 0] - np.float32(x_off)) / np.float32(x_sc) * np.float32(iw), (f[:, 1] - np.float32(y_off)) / np.float32(y_sc) * np.float32(ih),
+                  (f[:, 2] - np.float32(x_off)) / np.float32(x_sc) * np.float32(iw), (f[:, 3] - np.float32(y_off)) / np.float32(y_sc) * np.float32(ih)], 1)
+    assert np.array_equal(v.astype(np.float64).astype(np.int64), want)   # the restated chain reproduces the golden ints
+    d = got - want
+    bad = np.argwhere(d != 0)
+    span = np.maximum(np.abs(v).max(1), 1.0)                             # ulp scale: the box's largest coordinate in pixels
+    for (i, k) in bad:
+        assert abs(d[i, k]) == 1, (i, k, d[i, k])
+        dist = abs(v[i, k] - np.round(v[i, k]))
+        assert dist <= 8 * np.spacing(np.float32(span[i])), 'corner %d of box %d moved a pixel away from any integer boundary (v=%r)' % (k, i, v[i, k])
+    assert len(bad) <= max(2, 0.005 * 4 * n)
+    # suppression pattern == the reference's NMS run on the device's integer boxes and the reference's probabilities
+    rows = [list(got[i]) + [float(pre[i, 4])] + [float(c) for c in pre[i, 5:]] for i in range(n)]
+    host_oracle.do_nms(rows, 0.5)
+    exp_zero = np.array([r[5:] for r in rows]) == 0
     cls = res['classes'].cpu().numpy()
-    same_zero = (cls == 0) == (post[:, 5:] == 0)                        # NMS suppression pattern per class
-    assert same_zero.mean() >= 0.995, same_zero.mean()
+    assert np.array_equal(cls == 0, exp_zero)
+    if len(bad) == 0:
+        assert np.array_equal(cls == 0, post[:, 5:] == 0)
     nz = (cls != 0) & (post[:, 5:] != 0)
     np.testing.assert_allclose(cls[nz], post[:, 5:][nz], rtol=3e-7, atol=0)
     # do_nms really suppressed something in this fixture
-    assert ((g['pre'][:, 5:] != 0) & (post[:, 5:] == 0)).sum() > 10
+    assert ((pre[:, 5:] != 0) & (post[:, 5:] == 0)).sum() > 10
 
 
 def test_decode_nms_properties_at_full_size(model):
