@@ -15,12 +15,19 @@ channels).  achieved = algorithmic FLOPs of its launches / their HIP-event-timed
 instrumented steps right after the timed region (the timed steps themselves run un-instrumented).
 peak = 157.3 TFLOP/s, the dense fp32 MFMA rate of MI355X (MI355X_MICROARCH.md).
 `cpu_baseline`: the torch-CPU oracle restatement of the same step (kind "port"; the Keras/TF
-reference cannot run here) on a bounded sample, timed on this box's host cores.
+reference cannot run here) on a bounded sample, timed on this box's host cores; `detect_cpu` inside it is
+the detect path on the CPU (oracle forward at batch 1 + the single-core C oracle of decode/NMS).
+`loader_inclusive`: the same step fed by FaceDetector.train's real input path (JPEG decode on host
+threads, one pinned H2D copy and one fv_letterbox_batch launch per batch, GT encoding) from a synthetic
+UCCS-format folder -- reported beside `value`, never as `value`.
+N > 1: `multi_gpu` carries per-rank all-reduce time, the exposed communication (step minus a
+compute-only step) and the RCCL world size, so that a scaling run diagnoses itself.
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -32,6 +39,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s is what a float4 copy reaches)
 DOMINANT = 'conv_kernel<128,2,2,false>'
 HPS = dict(lr=1e-4, beta_1=0.99, beta_2=0.99, decay=0.0)  # reference face_vijnana_yolov3.json:12-15
+TRAFFIC_FILES = ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 
 
 def parse():
@@ -47,26 +55,78 @@ def parse():
     ap.add_argument('--no-overlap', action='store_true', help='serialise wgrad on the main stream (A/B aid)')
     ap.add_argument('--no-tail-split', action='store_true', help='conv launches without the tail split (A/B aid)')
     ap.add_argument('--no-detect', action='store_true', help='skip the detect-path measurement (PMC passes)')
+    ap.add_argument('--no-loader', action='store_true', help='skip the loader-inclusive measurement')
+    ap.add_argument('--loader-steps', type=int, default=6)
     return ap.parse_args()
 
 
+def host_cpu():
+    """CPU model string, physical cores and logical CPUs of this box (from /proc/cpuinfo)."""
+    model, cores = 'unknown', set()
+    try:
+        phys = core = None
+        for ln in open('/proc/cpuinfo'):
+            k, _, v = ln.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'model name':
+                model = v
+            elif k == 'physical id':
+                phys = v
+            elif k == 'core id':
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core)); phys = core = None
+    except OSError:
+        pass
+    return model, len(cores) or None, os.cpu_count()
+
+
 def cpu_baseline(batch, image_size):
-    """Torch-CPU oracle train step (fwd+bwd+Adam) on a bounded sample: `batch` images."""
+    """Torch-CPU oracle (the reference's arithmetic restated, kind 'port') on this box's host cores, on a
+    bounded sample: train step (fwd+bwd+Adam) at `batch` images, warm-up + timed samples; plus the detect
+    path on the CPU: oracle forward at batch 1 and the single-core C oracle of decode + NMS + top-k."""
+    import numpy as np
     import torch
     from oracle import net_oracle as no
+    from oracle import postproc as opp
     torch.manual_seed(0)
     p, st = no.init_params(7, torch.float32)
-    x = torch.rand((batch, image_size, image_size, 3))
     g = image_size // 32
-    yt = torch.rand((batch, g, g, 6))
     m = torch.zeros_like(p); v = torch.zeros_like(p)
-    t0 = time.time()
-    loss, grad, st = no.train_step_grads(p, st, x, yt)
-    p, m, v = no.keras_adam(p, grad, m, v, 0, **{k: HPS[k] for k in ('lr', 'beta_1', 'beta_2')})
-    dt = time.time() - t0
-    return dict(value=batch / dt, unit='images/sec', cores=torch.get_num_threads(), kind='port',
-                sample='1 train step (fwd+bwd+Adam) of the torch-CPU oracle at batch %d, %dx%d, fp32; %.1f s'
-                       % (batch, image_size, image_size, dt))
+
+    def step(b, s):
+        x = torch.rand((b, s, s, 3)); yt = torch.rand((b, s // 32, s // 32, 6))
+        t0 = time.perf_counter()
+        loss, grad, _ = no.train_step_grads(p, st, x, yt)
+        no.keras_adam(p, grad, m, v, 0, **{k: HPS[k] for k in ('lr', 'beta_1', 'beta_2')})
+        return time.perf_counter() - t0
+
+    step(1, 128)                                   # warm-up: thread pool, allocator, oneDNN primitives
+    t_train = [step(batch, image_size) for _ in range(2)]
+    x1 = torch.rand((1, image_size, image_size, 3))
+    with torch.no_grad():
+        no.forward(p, st, x1, training=False)
+        t_fwd = []
+        for _ in range(3):
+            t0 = time.perf_counter(); no.forward(p, st, x1, training=False); t_fwd.append(time.perf_counter() - t0)
+    rng = np.random.default_rng(99)
+    nf = 10000
+    head = np.zeros((nf, g, g, 6), np.float32)
+    head[..., 0] = rng.normal(0, 2, (nf, g, g)); head[..., 5] = rng.normal(0, 2, (nf, g, g))
+    head[..., 1:3] = rng.uniform(0, 1, (nf, g, g, 2)); head[..., 3:5] = rng.uniform(0, 0.3, (nf, g, g, 2))
+    opp.detect_postproc(head[:64], image_size, 0.5, 0.5, 60)
+    t0 = time.perf_counter(); opp.detect_postproc(head, image_size, 0.5, 0.5, 60); t_pp = time.perf_counter() - t0
+    model, phys, logical = host_cpu()
+    best = min(t_train)
+    return dict(value=round(batch / best, 4), unit='images/sec', cores=torch.get_num_threads(), kind='port',
+                cpu_model=model, physical_cores=phys, logical_cpus=logical,
+                samples_s=[round(t, 2) for t in t_train],
+                sample='train step (fwd+bwd+Adam) of the torch-CPU oracle at batch %d, %dx%d, fp32: 1 warm-up at 128x128 + %d timed '
+                       'samples, best taken; %d torch threads' % (batch, image_size, image_size, len(t_train), torch.get_num_threads()),
+                detect_cpu=dict(unit='ms/img', forward_batch1=round(min(t_fwd) * 1e3, 1), forward_threads=torch.get_num_threads(),
+                                postproc_c_oracle_1core=round(t_pp / nf * 1e3, 5),
+                                sample='oracle forward (inference BN) at batch 1, best of 3; C oracle decode+NMS+top-k over the %d '
+                                       'config-4 frames on one core' % nf))
 
 
 def detect_bench(eng, x40):
@@ -91,25 +151,97 @@ def detect_bench(eng, x40):
     one = lambda xb: decode_nms(eng.ctx, eng.predict_device(xb), S, 0.5, 0.5, 60)
     t1 = timed(lambda: one(x1), 20)
     t40 = timed(lambda: one(x40), 5)
-    import time as _t
-    t0 = _t.perf_counter()
+    t0 = time.perf_counter()
     for _ in range(20):
         to_boundboxes(one(x1), 0)           # end to end incl. D2H + BoundBox objects, as detect() returns
-    e2e = (_t.perf_counter() - t0) / 20 * 1e3
+    e2e = (time.perf_counter() - t0) / 20 * 1e3
     rng = np.random.default_rng(99)
-    head = np.zeros((10000, 13, 13, 6), np.float32)
-    head[..., 0] = rng.normal(0, 2, (10000, 13, 13)); head[..., 5] = rng.normal(0, 2, (10000, 13, 13))
-    head[..., 1:3] = rng.uniform(0, 1, (10000, 13, 13, 2)); head[..., 3:5] = rng.uniform(0, 0.3, (10000, 13, 13, 2))
+    g = S // 32
+    head = np.zeros((10000, g, g, 6), np.float32)
+    head[..., 0] = rng.normal(0, 2, (10000, g, g)); head[..., 5] = rng.normal(0, 2, (10000, g, g))
+    head[..., 1:3] = rng.uniform(0, 1, (10000, g, g, 2)); head[..., 3:5] = rng.uniform(0, 0.3, (10000, g, g, 2))
     hd = torch.from_numpy(head).cuda()
-    tpp = timed(lambda: decode_nms(eng.ctx, hd, 416, 0.5, 0.5, 60), 10)
+    tpp = timed(lambda: decode_nms(eng.ctx, hd, S, 0.5, 0.5, 60), 10)
     return dict(unit='ms/img', batch1_device=round(t1, 4), batch1_end_to_end=round(e2e, 4),
                 batch40_device=round(t40 / x40.shape[0], 4), postproc_10k_frames=round(tpp / 10000, 6),
                 postproc_10k_total_ms=round(tpp, 3))
 
 
+def loader_bench(eng, trainer, B, S, steps):
+    """SURVEY 8d config 2 'data-loader-inclusive number': FaceDetector.train's input path + the step."""
+    import numpy as np
+    import torch
+    from face_vijnana_yolov3_amd import data
+    from face_vijnana_yolov3_amd.face_detection import BatchFeeder, train_on_item
+    with tempfile.TemporaryDirectory() as root:
+        n_img = 2 * B
+        rng = np.random.default_rng(0)
+        sizes = [(768, 1024), (1024, 768), (720, 1280), (600, 800)]
+        from PIL import Image
+        rows, fid = [], 0
+        for k in range(n_img):
+            h, w = sizes[k % len(sizes)]
+            lo = rng.integers(0, 256, (h // 16 + 1, w // 16 + 1, 3), dtype=np.uint8)     # photo-like spectrum, not white noise
+            im = Image.fromarray(lo).resize((w, h), Image.BICUBIC)
+            name = 'img_%04d.jpg' % k
+            im.save(os.path.join(root, name), quality=90)
+            for _ in range(int(rng.integers(1, 6))):
+                fw = float(rng.uniform(20, w / 4)); fh = float(rng.uniform(20, h / 4))
+                rows.append([fid, name, 1, round(float(rng.uniform(1, w - fw - 1)), 1), round(float(rng.uniform(1, h - fh - 1)), 1), round(fw, 1), round(fh, 1)])
+                fid += 1
+        import pandas as pd
+        pd.DataFrame(rows, columns=data.CSV_COLUMNS).to_csv(os.path.join(root, 'training.csv'), index=False)
+        hps = dict(HPS, batch_size=B, step=1)
+        seq = data.TrainingSequence(root, hps, {'image_size': S, 'bb_info_c_size': 6})
+        threads = min(16, max(2, (os.cpu_count() or 8) // 2))
+        feeder = BatchFeeder(seq, 1, 0, threads)
+        t0 = time.perf_counter()
+        for k in range(2):
+            feeder.load(k % len(seq))
+        loader_only = 2 * B / (time.perf_counter() - t0)
+        feeder.prefetch(0)
+        for k in range(2):                             # warm-up
+            item = feeder.take(); feeder.prefetch((k + 1) % len(seq))
+            train_on_item(eng, trainer, item, S, hps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            item = feeder.take(); feeder.prefetch((k + 1) % len(seq))
+            train_on_item(eng, trainer, item, S, hps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        feeder.take(); feeder.close()
+    return dict(value=round(B * steps / dt, 2), unit='images/sec', ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
+                loader_only_images_per_sec=round(loader_only, 1), loader_threads=threads,
+                path='%d synthetic UCCS-format JPEGs (768x1024 .. 720x1280): PIL decode on host threads -> one pinned buffer -> '
+                     'H2D -> fv_letterbox_batch (one launch) -> fv_train_step + Adam; batch k+1 decoded while step k runs' % n_img)
+
+
+def pmc_traffic(B, S):
+    """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes --
+    only if the kernel sources are still the ones that were profiled (fingerprint recorded with the pass)."""
+    from face_vijnana_yolov3_amd.build import source_fingerprint
+    for name in TRAFFIC_FILES:
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', name)))
+        except (OSError, ValueError):
+            continue
+        tk = tj.get('conv_kernel<128, 2, 2, false>')
+        if not tk or B != PER_GPU_BATCH or S != IMAGE_SIZE:
+            return None, None
+        if tj.get('_source_fingerprint') != source_fingerprint():
+            return None, 'profiles/%s was taken on other kernel sources (fingerprint %s, now %s): traffic not reported' % (
+                name, tj.get('_source_fingerprint'), source_fingerprint())
+        return round((tk['fetch_MB_per_launch'] + tk['write_MB_per_launch']) * 1e6), (
+            'profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 (gfx950 correction); '
+            'fabric-side requests, Infinity-Cache hits included' % name)
+    return None, None
+
+
 def main():
     args = parse()
     import torch
+    import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -122,7 +254,7 @@ def main():
                          '--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...' % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     from face_vijnana_yolov3_amd import data
-    from face_vijnana_yolov3_amd.engine import Engine
+    from face_vijnana_yolov3_amd.engine import Engine, train_flops_per_image
     from face_vijnana_yolov3_amd.parallel import DataParallelTrainer
 
     eng = Engine(local_rank)
@@ -153,6 +285,32 @@ def main():
     dt = trainer.max_over_ranks(dt)
     loss_v = float(loss.item())
 
+    # ---- N > 1: what the communication costs (every rank measures, rank 0 reports all of them)
+    multi = None
+    if world > 1:
+        k = max(3, min(args.steps, 10))
+        trainer.time_comm = True
+        trainer.comm_ms()
+        for _ in range(k):
+            step()
+        allreduce_ms = trainer.comm_ms() / k
+        trainer.time_comm = False
+        torch.cuda.synchronize(); trainer.barrier()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            eng.train_on_batch(x, y, **HPS)          # the same step without any collective (replicas diverge in rounding only;
+        torch.cuda.synchronize()                     # nothing is measured after this block that depends on the weights)
+        compute_ms = (time.perf_counter() - t1) / k * 1e3
+        mine = dict(rank=rank, allreduce_ms=round(allreduce_ms, 3), compute_only_ms=round(compute_ms, 3),
+                    exposed_comm_ms=round(dt / args.steps * 1e3 - compute_ms, 3))
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        multi = dict(rccl_ranks=dist.get_world_size(), backend=dist.get_backend(), bucket_mib=trainer.bucket_bytes >> 20,
+                     gradient_mb=round(eng.n_params * 4 / 1e6, 2), per_rank=allr)
+        for t in (eng.params, eng.state, eng.m, eng.v):
+            dist.broadcast(t, 0)
+        trainer.barrier()
+
     # instrumented steps for the roofline of the dominant kernel (HIP events on the launch stream).
     # They run with fv_set_overlap(0): under the backward overlap two MFMA kernels time-share the
     # chip and a launch's elapsed time is no longer that kernel's own rate (the timed region above
@@ -177,19 +335,12 @@ def main():
     out = None
     if rank == 0:
         detect = None if args.no_detect else detect_bench(eng, x)
+        loader = None
+        if world == 1 and not args.no_loader:
+            loader = loader_bench(eng, trainer, B, S, args.loader_steps)
         dom = prof.get(DOMINANT)
         roofline = None
-        traffic = None   # HBM-side bytes per launch from committed rocprofv3 PMC passes (cannot be read live)
-        try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-            tk = tj.get('conv_kernel<128, 2, 2, false>')
-            if tk and B == PER_GPU_BATCH and S == IMAGE_SIZE:
-                traffic = round((tk['fetch_MB_per_launch'] + tk['write_MB_per_launch']) * 1e6)   # bytes per launch
-        except (OSError, ValueError, KeyError):
-            pass
-        traffic_source = None if traffic is None else (
-            'profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 '
-            '(gfx950 correction); fabric-side requests, Infinity-Cache hits included')
+        traffic, traffic_source = pmc_traffic(B, S)
         if dom and dom['ms'] > 0:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
             roofline = dict(bound='mfma', achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
@@ -205,17 +356,14 @@ def main():
                            tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['flops'] and v['ms'] else None,
                            gbps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] else None)
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
-        from oracle import net_oracle as no
-        fwd = no.fwd_flops_per_image(S)
-        conv0 = 2 * S * S * 27 * 32
-        train_flops = 3 * fwd - conv0  # fwd + wgrad(all) + dgrad(all but conv_0)
+        train_flops = train_flops_per_image(S)       # fwd + wgrad(all) + dgrad(all but conv_0)
         ips = world * B * args.steps / dt
         out = {
-            'metric': 'training images/sec (416x416 bs=40 per GPU)', 'value': round(ips, 2), 'unit': 'images/sec',
+            'metric': 'training images/sec (%dx%d bs=%d per GPU)' % (S, S, B), 'value': round(ips, 2), 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'FaceDetector mode=train image_size=%d batch_size=%d per GPU, synthetic UCCS-shaped '
-                                   'batch, random-init Darknet-53 base + 13x13x6 head, MSE, Adam lr 1e-4 b1=b2=0.99' % (S, B),
+                                   'batch, random-init Darknet-53 base + %dx%dx6 head, MSE, Adam lr 1e-4 b1=b2=0.99' % (S, B, S // 32, S // 32),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world},
             'loss': loss_v,
             'step_tflops_per_gpu': round(train_flops * B * args.steps / dt / 1e12, 2),
@@ -229,6 +377,8 @@ def main():
                              for k, v in kernels.items()
                              if k in ('bn_act_stats_kernel', 'bn_bwd_apply_slots_kernel', 'bn_bwd_reduce_kernel', 'adam_kernel') and v['gbps']},
             'detect': detect,
+            'loader_inclusive': loader,
+            'multi_gpu': multi,
             'kernels': kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -19,6 +19,16 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=o
          '-Wno-unused-function', '-Wno-unused-variable']
 
 
+def source_fingerprint():
+    """sha1 over the kernel sources: profiles/*_pmc_traffic.json records it, and bench.py reports the
+    measured HBM traffic only while the kernels are still the ones that were profiled."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.h'))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

@@ -1,5 +1,6 @@
 // Context management of the C ABI (include/fv_hotpath.h).
 #include <cstdarg>
+#include <cstdlib>
 #include "common.h"
 
 static thread_local std::string g_create_err;
@@ -122,7 +123,17 @@ int fv_create(int device, void* stream, fv_ctx** out) {
     fv_ctx* c = new fv_ctx();
     c->device = device;
     c->stream = (hipStream_t)stream;
-    bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+    // The side stream carries the weight-gradient kernels of the backward overlap.  FV_SIDE_PRIORITY=low|high
+    // (experiment knob) creates it with the lowest / highest stream priority instead of the default.
+    bool ok;
+    {
+        const char* pr = getenv("FV_SIDE_PRIORITY");
+        int least = 0, greatest = 0;
+        if (pr && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && (pr[0] == 'l' || pr[0] == 'h'))
+            ok = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, pr[0] == 'l' ? least : greatest) == hipSuccess;
+        else
+            ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+    }
     for (int i = 0; i < 2 && ok; ++i)
         ok = hipEventCreateWithFlags(&c->ev_dz[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_wg[i], hipEventDisableTiming) == hipSuccess;

@@ -13,7 +13,10 @@ int fv_ew_bn_bwd_chunks(long long rows, int C);
 int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale, const float* shift, const float* mean,
                  const float* invstd, long long rows, int C, float leaky, float* pdb, float* pdg, float* dbeta, float* dgamma,
                  float* dz, double* slots = nullptr, int nslot = 0, bool reduced = false);
-int fv_ew_mse(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int Cpad, float* loss, float* dy, float* dbias);
+// part != NULL: multi-workgroup form with fv_ew_mse_scratch_floats() floats of scratch (8-byte aligned); NULL: one workgroup
+int fv_ew_mse(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int Cpad, float* loss, float* dy, float* dbias,
+              double* part = nullptr);
+int fv_ew_mse_scratch_floats();
 int fv_ew_adam(fv_ctx* ctx, float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2, float eps);
 // training-mode BN without a finalize launch: the conv epilogue adds its column sums to
 // [nslot][2][C] fp64 accumulator slots (zeroed by the caller); this pass sums them, normalises, and

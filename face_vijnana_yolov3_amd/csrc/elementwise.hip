@@ -352,6 +352,50 @@ __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ yp,
     }
 }
 
+// The same over many workgroups (the training step's form): a workgroup = 8 row lanes x 32 columns owns the
+// rows b*8 + lane, stepping by 8*gridDim.x; it writes its rows of dy and leaves one partial (sum of squares, column
+// sums, all in double) in part[b][0..32]; mse_finish_kernel adds the partials in workgroup order: deterministic.
+constexpr int MSE_G = 64;
+__global__ __launch_bounds__(256) void mse_part_kernel(const float* __restrict__ yp, const float* __restrict__ yt, int rows, int C,
+                                                       int Cpad, float grad_scale, float* __restrict__ dy, double* __restrict__ part) {
+    __shared__ double s_col[8][33];
+    __shared__ double s_acc[4];
+    const int tid = threadIdx.x, c = tid & 31, rl = tid >> 5;
+    double acc = 0.0, col = 0.0;
+    for (int r = blockIdx.x * 8 + rl; r < rows; r += 8 * gridDim.x) {
+        float d = 0.f;
+        if (c < C) {
+            const float e = yp[(size_t)r * C + c] - yt[(size_t)r * C + c];
+            acc += (double)e * (double)e;
+            d = e * grad_scale;
+            col += (double)d;
+        }
+        for (int cc = c; cc < Cpad; cc += 32) dy[(size_t)r * Cpad + cc] = cc < C ? d : 0.f;
+    }
+    // wave reduction of the squared error (64 lanes = 2 row lanes x 32 columns), then the 4 waves
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((tid & 63) == 0) s_acc[tid >> 6] = acc;
+    s_col[rl][c] = col;
+    __syncthreads();
+    if (tid < 32) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += s_col[k][tid];
+        part[(size_t)blockIdx.x * 33 + 1 + tid] = s;
+        if (tid == 0) part[(size_t)blockIdx.x * 33] = (s_acc[0] + s_acc[1]) + (s_acc[2] + s_acc[3]);
+    }
+}
+__global__ __launch_bounds__(64) void mse_finish_kernel(const double* __restrict__ part, int nblk, int C, double inv_n,
+                                                        float* __restrict__ loss, float* __restrict__ dbias) {
+    const int t = threadIdx.x;
+    if (t > 32) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * 33 + t];
+    if (t == 0) *loss = (float)(s * inv_n);
+    else if (t - 1 < C && dbias) dbias[t - 1] = (float)s;
+}
+
 // ---------------------------------------------------------------- fd_loss (reference fd.py:59-64; defined there, never used)
 // per cell: (BCE(y0,p0) + mean_{1..4} sqrt((y-p)^2) + BCE(y5,p5)) / 3 with Keras' probability-space BCE
 // (p clipped to [1e-7, 1-1e-7]); loss = mean over cells.  Gradient: (p-y)/(p(1-p)) inside the clip range, 0 outside;
@@ -587,9 +631,20 @@ int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale
     return FV_OK;
 }
 
-int fv_ew_mse(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int Cpad, float* loss, float* dy, float* dbias) {
+int fv_ew_mse_scratch_floats() { return 2 * MSE_G * 33; }
+
+int fv_ew_mse(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int Cpad, float* loss, float* dy, float* dbias,
+              double* part) {
     FV_REQUIRE(ctx, C <= 32 && Cpad >= C, "mse: C must be <= 32");
     float gs = (float)(2.0 / ((double)rows * C));
+    if (part) {
+        const int g = (rows + 7) / 8 < MSE_G ? (rows + 7) / 8 : MSE_G;
+        hipLaunchKernelGGL(mse_part_kernel, dim3(g), dim3(256), 0, ctx->stream, yp, yt, rows, C, Cpad, gs, dy, part);
+        FV_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, part, g, C, 1.0 / ((double)rows * C), loss, dbias);
+        FV_LAUNCH_CHECK(ctx);
+        return FV_OK;
+    }
     hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, ctx->stream, yp, yt, rows, C, Cpad, gs, loss, dy, dbias);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;

@@ -72,7 +72,8 @@ struct Plan {
     std::vector<double*> slots, bslots;   // per layer [nslot][2][cout] fp64 accumulators, forward statistics and
                                           // backward d-beta/d-gamma (one contiguous range over all layers)
     size_t slots_bytes;
-    float *w0p, *yhat, *dyp, *G[3], *D[2], *loss, *slab, *tail;
+    float *w0p, *yhat, *dyp, *G[3], *D[2], *loss, *slab, *tail, *mse_part, *head_slab;
+    int head_ks;
     size_t tail_floats;
     size_t bytes;
 };
@@ -145,6 +146,10 @@ Plan make_plan(void* base, int B, int S, bool training) {
         for (int i = 0; i < 2; ++i) p.G[i] = c.take(max_act);   // activation gradients (ping-pong + kept block gradient)
         for (int i = 0; i < 2; ++i) p.D[i] = c.take(max_act);   // dz of layer l lives in D[l&1] until its wgrad has run
         p.loss = c.take(64);
+        p.mse_part = c.take(fv_ew_mse_scratch_floats());
+        // the head conv has 6 output channels: 53 tiles of 288 K steps -- K-split it like the batch-1 inference path
+        p.head_ks = fv_conv_choose_ksplit(B * G * G, HEAD_C, 9 * 1024 / 32);
+        p.head_slab = p.head_ks > 1 ? c.take((size_t)p.head_ks * B * G * G * HEAD_C) : nullptr;
     } else {
         for (int i = 0; i < 3; ++i) p.G[i] = c.take(max_act);
         // K-split partial slabs of the small-M layers (batch-1 latency path)
@@ -329,10 +334,17 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
     const auto& h = N.L[nb];
     const int G = S / h.in_div;
     const int hrows = batch * G * G;
-    if (int rc = fv_op_conv_forward(ctx, cur, params + h.w_off, batch, G, G, h.cin, h.cout, 3, 1, FV_EPI_AFFINE, nullptr,
-                                    params + h.beta_off, 0.f, nullptr, p.yhat, nullptr, nullptr)) return rc;
+    if (p.head_ks > 1) {
+        if (int rc = fv_op_conv_forward(ctx, cur, params + h.w_off, batch, G, G, h.cin, h.cout, 3, 1, 0, nullptr, nullptr, 0.f,
+                                        nullptr, p.head_slab, nullptr, nullptr, p.head_ks)) return rc;
+        if (int rc = fv_ew_splitk_finish(ctx, p.head_slab, p.head_ks, (long long)hrows * h.cout, nullptr, params + h.beta_off, nullptr,
+                                         p.yhat, (long long)hrows * h.cout, h.cout, 0.f, 0)) return rc;
+    } else {
+        if (int rc = fv_op_conv_forward(ctx, cur, params + h.w_off, batch, G, G, h.cin, h.cout, 3, 1, FV_EPI_AFFINE, nullptr,
+                                        params + h.beta_off, 0.f, nullptr, p.yhat, nullptr, nullptr)) return rc;
+    }
     // ---------------- loss + its gradient (fd.py:381 'mse')
-    if (int rc = fv_ew_mse(ctx, p.yhat, y_true, hrows, HEAD_C, HEAD_PAD, loss, p.dyp, grads + h.beta_off)) return rc;
+    if (int rc = fv_ew_mse(ctx, p.yhat, y_true, hrows, HEAD_C, HEAD_PAD, loss, p.dyp, grads + h.beta_off, (double*)p.mse_part)) return rc;
 
     // ---------------- backward
     if (int rc = fv_op_conv_wgrad(ctx, p.a[nb - 1], p.dyp, batch, G, G, h.cin, h.cout, HEAD_PAD, 3, 1, grads + h.w_off)) return rc;

@@ -24,6 +24,16 @@ def layer_table():
     return out
 
 
+def fwd_flops_per_image(image_size=416):
+    """2*MAC of the 52 base convs + the head at one image (49.050 GFLOP at 416)."""
+    return sum(2 * (image_size // d['out_div']) ** 2 * d['ksize'] ** 2 * d['cin'] * d['cout'] for d in layer_table())
+
+
+def train_flops_per_image(image_size=416):
+    """forward + every weight-gradient + every data-gradient except conv_0's (146.85 GFLOP at 416)."""
+    return 3 * fwd_flops_per_image(image_size) - 2 * image_size * image_size * 27 * 32
+
+
 class Engine(object):
     def __init__(self, device=0, stream=None):
         self.ctx = Context(device, stream)

@@ -95,51 +95,30 @@ class FaceDetector(object):
 
     # ------------------------------------------------------------------ train (fd.py:602-630)
     def train(self):
-        import torch
-        from .parallel import DataParallelTrainer, slice_batch
+        from .parallel import DataParallelTrainer
         seq = self.TrainingSequence(self.raw_data_path, self.hps, self.nn_arch, self.grid, self.cell_image_size)
         trainer = DataParallelTrainer(self.model, world_size=self.world, rank=self.rank)
         hp = self.hps
         steps = len(seq)
         rng = np.random.default_rng(0)
-        pool = ThreadPoolExecutor(max_workers=int(hp.get('loader_threads', 8)))
-
-        def load(index):
-            """Loader side (host threads, as the reference's Keras Sequence workers): this rank's tower
-            slice of the batch -- JPEG decode, GT encoding, and the decoded images packed back to back
-            in one pinned buffer; the letterbox itself runs on the device in one launch."""
-            names = seq.file_names[index * seq.batch_size:(index + 1) * seq.batch_size]
-            sl = slice_batch(len(names), self.world, self.rank) if self.world > 1 else (0, len(names), 1.0)
-            if sl is None:
-                return None            # fewer images than ranks: skipped on every rank alike
-            lo, hi, weight = sl
-            raws = list(pool.map(lambda nm: seq.loader(os.path.join(seq.raw_data_path, nm)), names[lo:hi]))
-            y = np.asarray([data.encode_gt(seq.groups[nm].iloc[:, 3:7].values, r.shape[0], r.shape[1], seq.image_size, seq.grid,
-                                           seq.nn_arch['bb_info_c_size']) for nm, r in zip(names[lo:hi], raws)], np.float32)
-            return pack_images(raws), torch.from_numpy(y).pin_memory(), weight
-
-        feeder = ThreadPoolExecutor(max_workers=1)
+        feeder = BatchFeeder(seq, self.world, self.rank, int(hp.get('loader_threads', 8)))
         for epoch in range(hp['epochs']):
             order = rng.permutation(steps)  # Keras fit_generator shuffles batch order (shuffle=True)
             if self.rank == 0:
                 print('Epoch %d/%d' % (epoch + 1, hp['epochs']))
-            nxt = feeder.submit(load, int(order[0]))
+            feeder.prefetch(int(order[0]))
             for k in range(steps):
-                item = nxt.result()
+                item = feeder.take()
                 if k + 1 < steps:
-                    nxt = feeder.submit(load, int(order[k + 1]))   # decode of batch k+1 overlaps step k
+                    feeder.prefetch(int(order[k + 1]))   # decode of batch k+1 overlaps step k
                 if item is None:
                     if self.rank == 0:
                         print('%d/%d - skipped (fewer images than ranks)' % (k + 1, steps))
                     continue
-                packed, y, weight = item
-                x, _ = letterbox_batch_device(self.model.ctx, None, self.image_size, self.model.dev, packed=packed)
-                loss = trainer.train_on_batch(x, y.to(self.model.dev, non_blocking=True), hp['lr'], hp['beta_1'],
-                                              hp['beta_2'], hp.get('decay', 0.0), weight=weight)
+                loss = train_on_item(self.model, trainer, item, self.image_size, hp)
                 if self.rank == 0 and (DEBUG or k + 1 == steps):
                     print('%d/%d - loss: %.4f' % (k + 1, steps, float(loss.item())))
-        feeder.shutdown()
-        pool.shutdown()
+        feeder.close()
         if self.rank == 0:
             print('Save the model.')
             self.model.save(self.MODEL_PATH)
@@ -261,6 +240,53 @@ class FaceDetector(object):
                 _raw, boxes = self._run_file(file_name)
                 self._write_rows(f, file_name, boxes)
         merge_rank_files(out_path, self.world, self.rank)
+
+
+class BatchFeeder(object):
+    """Loader side of train() -- the role of the reference's Keras Sequence workers (fd.py:75-310,
+    fit_generator(workers=4|8) fd.py:621-627): for batch `index`, this rank's tower slice is JPEG-decoded
+    by a thread pool (PIL releases the GIL), its GT tensors are encoded, and the decoded images are
+    packed back to back into one pinned host buffer.  Resize + pad happen on the device, in one launch
+    per batch (fv_letterbox_batch).  One batch is prepared ahead while the previous step runs."""
+
+    def __init__(self, seq, world, rank, threads=8):
+        self.seq, self.world, self.rank = seq, world, rank
+        self.pool = ThreadPoolExecutor(max_workers=max(1, threads))
+        self.one = ThreadPoolExecutor(max_workers=1)
+        self.pending = None
+
+    def load(self, index):
+        import torch
+        from .parallel import slice_batch
+        seq = self.seq
+        names = seq.file_names[index * seq.batch_size:(index + 1) * seq.batch_size]
+        sl = slice_batch(len(names), self.world, self.rank) if self.world > 1 else (0, len(names), 1.0)
+        if sl is None:
+            return None            # fewer images than ranks: skipped on every rank alike
+        lo, hi, weight = sl
+        raws = list(self.pool.map(lambda nm: seq.loader(os.path.join(seq.raw_data_path, nm)), names[lo:hi]))
+        y = np.asarray([data.encode_gt(seq.groups[nm].iloc[:, 3:7].values, r.shape[0], r.shape[1], seq.image_size, seq.grid,
+                                       seq.nn_arch['bb_info_c_size']) for nm, r in zip(names[lo:hi], raws)], np.float32)
+        yt = torch.from_numpy(y)
+        return pack_images(raws), (yt.pin_memory() if torch.cuda.is_available() else yt), weight
+
+    def prefetch(self, index):
+        self.pending = self.one.submit(self.load, index)
+
+    def take(self):
+        return self.pending.result()
+
+    def close(self):
+        self.one.shutdown(); self.pool.shutdown()
+
+
+def train_on_item(engine, trainer, item, image_size, hp):
+    """One optimisation step on what BatchFeeder.load returned: H2D copy, device letterbox, fv_train_step
+    (+ gradient all-reduce when world > 1), Adam."""
+    packed, y, weight = item
+    x, _ = letterbox_batch_device(engine.ctx, None, image_size, engine.dev, packed=packed)
+    return trainer.train_on_batch(x, y.to(engine.dev, non_blocking=True), hp['lr'], hp['beta_1'], hp['beta_2'],
+                                  hp.get('decay', 0.0), weight=weight)
 
 
 def _font():

@@ -60,6 +60,27 @@ def main():
             d = traffic.setdefault(k, {})
             d['launches_in_2_steps'] = n
             d[key] = round(v * mult / 1024.0 / n, 2)
+    fp = os.path.join(g, '%s_fingerprint.txt' % tag)
+    if os.path.exists(fp):
+        traffic['_source_fingerprint'] = open(fp).read().strip()   # bench.py reports traffic only while the kernels are these
+    mf = glob.glob(os.path.join(g, '%s_pmc_mfma' % tag, '**', '*counter_collection.csv'), recursive=True)
+    if mf:
+        # MfmaUtil per kernel = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) -- the counter sums over
+        # all SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs (MI355X_MICROARCH.md, rocprofv3 PMC section)
+        acc = {}
+        for r in csv.DictReader(open(mf[0])):
+            a = acc.setdefault(short(r['Kernel_Name']), {'n': 0})
+            a[r['Counter_Name']] = a.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+            a['n'] += 1
+        util = {}
+        for k, a in acc.items():
+            if a.get('GRBM_GUI_ACTIVE'):
+                util[k] = dict(mfma_busy_cycles=a.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0), gui_active=a['GRBM_GUI_ACTIVE'],
+                               mfma_util=round(a.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (a['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0), 4))
+        json.dump(util, open(os.path.join(p, '%s_pmc_mfma_util.json' % out), 'w'), indent=1)
+        for k in ('conv_kernel<128, 2, 2, false>', 'wgrad_kernel<128, 128, true, false>'):
+            if k in util:
+                print('MfmaUtil', k, util[k]['mfma_util'])
     traffic['_note'] = ('rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes over: bench.py --steps 1 '
                         '--warmup 1 --no-cpu-baseline --profile-steps 0 --no-overlap --no-detect; MB per launch; FETCH_SIZE '
                         'doubled (gfx950 correction); fabric-side requests, Infinity-Cache hits included')
