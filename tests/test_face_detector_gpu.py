@@ -152,7 +152,15 @@ def test_csv_rows_match_the_reference_test_golden(tmp_path, monkeypatch, golden_
     for k, f in enumerate(files):
         want = str(g['rows'][k]).split('\n') if str(g['rows'][k]) else []
         got = [ln for ln in text if ln.split(',')[0] == f]
-        assert got == want, (f, got[:2], want[:2])
+        assert len(got) == len(want), (f, len(got), len(want))
+        for a, b in zip(got, want):
+            # name, x, y, w, h: text-identical.  score: the float32 product of two sigmoids, where NumPy's SIMD
+            # float32 exp and the kernel's correctly rounded exp may differ in the last place (as in
+            # tests/test_postproc_gpu.py: scores within 2 ulp, everything else bit-exact)
+            assert a.rsplit(',', 1)[0] == b.rsplit(',', 1)[0], (f, a, b)
+            sa, sb = np.float32(a.rsplit(',', 1)[1]), np.float32(b.rsplit(',', 1)[1])
+            assert abs(float(sa) - float(sb)) <= 2 * float(np.spacing(sb)), (f, a, b)
+            assert float(a.rsplit(',', 1)[1]) == float(sa)         # printed as the float64 of a float32, like the reference
     assert sum(len(str(r).split('\n')) for r in g['rows'] if str(r)) == len(text)
     # evaluate() writes the same rows (same code path in the reference, fd.py:700-738)
     import pandas as pd
