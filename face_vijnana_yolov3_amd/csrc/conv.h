@@ -11,6 +11,21 @@ struct FvTaps {
     int wslot[9];
 };
 
+// "Virtual" BN-backward operand: instead of a materialised dz = dL/d(pre-BN output) tensor, a kernel is given g = dL/d(activated
+// output) and the layer's pre-BN tensor z (same layout) plus six per-channel vectors, and forms
+//     dz = scale * ((g * leaky'(z*scale+shift) - dbm) - ((z - mean) * invstd) * dgm),     dbm = d-beta / rows, dgm = d-gamma / rows
+// while staging the operand -- bit for bit what bn_bwd_apply_slots_kernel would have written, so the separate apply pass
+// (12 B per element of HBM traffic, fully exposed) disappears.  Elements outside the image / problem stay zero.
+struct FvVirtDz {
+    const float* z;        // NULL: plain operand
+    const float *scale, *shift, *mean, *invstd, *dbm, *dgm;
+    float leaky;
+};
+__device__ __forceinline__ float fv_virt_dz1(float g, float z, float sc, float sh, float mu, float is, float dbm, float dgm, float leaky) {
+    const float gy = (z * sc + sh) > 0.f ? g : g * leaky;
+    return sc * (gy - dbm - (z - mu) * is * dgm);
+}
+
 enum { FV_EPI_AFFINE = 1, FV_EPI_LEAKY = 2, FV_EPI_ADD = 4, FV_EPI_STATS = 8, FV_EPI_BNRED = 16 };
 
 // Gather-convolution:  out[b, oh*os+oph, ow*os+opw, n] = sum_{t,c} x[b, oh*is+dh[t], ow*is+dw[t], c] * w[n][wslot[t]][c]
@@ -50,6 +65,7 @@ struct FvConvArgs {
     int ksplit;        // >1: blockIdx.y owns a slice of the K steps and stores its raw partial to out + y*split_stride
     long long split_stride;
     int oph[4], opw[4];
+    FvVirtDz virt;     // x is g, staged as dz (see FvVirtDz); virt.z == NULL: x is used as it is
     FvTaps taps[4];
 };
 
@@ -76,6 +92,7 @@ struct FvWgradArgs {
     int Tw;                // taps per output channel in dw
     int M;                 // B*Hl*Wl
     double alg_flops;      // algorithmic 2*MAC of this launch (profiling only)
+    FvVirtDz virt;         // dy is g, staged as dz (see FvVirtDz)
     FvTaps taps;
 };
 int fv_wgrad_launch(fv_ctx* ctx, const FvWgradArgs& a);

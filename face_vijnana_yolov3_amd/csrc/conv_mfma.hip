@@ -90,8 +90,9 @@ __device__ __forceinline__ void stat_store(const FvConvArgs& a, int mt, int n, f
     }
 }
 
-template <int BN, int WAVES_M, int WAVES_N, bool GATHER>
+template <int BN, int WAVES_M, int WAVES_N, bool GATHER, bool VIRT = false>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
+    static_assert(!(GATHER && VIRT), "the gathered first layer has no data-gradient");
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int MB = WTM / 32, NB = WTN / 32;
     constexpr int BL = BN / 32;  // B-tile float4 loads per thread
@@ -235,6 +236,13 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
         for (int p = 0; p < 4; ++p) ra[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
         for (int p = 0; p < BL; ++p) rb[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
 #endif
+        // VIRT: x is g; the matching z rows and this K step's six per-channel vectors travel with the operand loads and the
+        // staged value is dz (FvVirtDz) -- zero where the tap is outside the image (a_off == OOB), like the plain operand
+        const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(VIRT ? a.virt.z : a.x), 0, (int)((unsigned)a.B * a.Hin * a.Win * a.Cin * 4u), 0x00020000);
+        u32x4 rz[VIRT ? 4 : 1];
+        float4 vsc, vsh, vmu, vis, vdb, vdg;
+        unsigned st_off[4];   // a_off of the loaded (not yet staged) step: advance() may move a_off before stage()
         unsigned a_off[4];
         int t = s_begin / cpk, ci = s_begin - t * cpk;
         auto set_tap = [&](int tp) {
@@ -259,13 +267,37 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
 #endif
 #pragma unroll
             for (int p = 0; p < 4; ++p) ra[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, a_off[p], c0b, 0);
+            if constexpr (VIRT) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { rz[p] = __builtin_amdgcn_raw_buffer_load_b128(zr, a_off[p], c0b, 0); st_off[p] = a_off[p]; }
+                const int kc = ci * BK + col4;
+                vsc = *reinterpret_cast<const float4*>(a.virt.scale + kc); vsh = *reinterpret_cast<const float4*>(a.virt.shift + kc);
+                vmu = *reinterpret_cast<const float4*>(a.virt.mean + kc); vis = *reinterpret_cast<const float4*>(a.virt.invstd + kc);
+                vdb = *reinterpret_cast<const float4*>(a.virt.dbm + kc); vdg = *reinterpret_cast<const float4*>(a.virt.dgm + kc);
+            }
 #pragma unroll
             for (int p = 0; p < BL; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_row[p], wofs, 0);
         };
         auto stage = [&](int buf) {
+            if constexpr (VIRT) {
+                const float lk = a.virt.leaky;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const bool ok = st_off[p] != OOB;
+                    const float g0 = __uint_as_float(ra[p].x), g1 = __uint_as_float(ra[p].y), g2 = __uint_as_float(ra[p].z), g3 = __uint_as_float(ra[p].w);
+                    const float z0 = __uint_as_float(rz[p].x), z1 = __uint_as_float(rz[p].y), z2 = __uint_as_float(rz[p].z), z3 = __uint_as_float(rz[p].w);
+                    float4 v;
+                    v.x = ok ? fv_virt_dz1(g0, z0, vsc.x, vsh.x, vmu.x, vis.x, vdb.x, vdg.x, lk) : 0.f;
+                    v.y = ok ? fv_virt_dz1(g1, z1, vsc.y, vsh.y, vmu.y, vis.y, vdb.y, vdg.y, lk) : 0.f;
+                    v.z = ok ? fv_virt_dz1(g2, z2, vsc.z, vsh.z, vmu.z, vis.z, vdb.z, vdg.z, lk) : 0.f;
+                    v.w = ok ? fv_virt_dz1(g3, z3, vsc.w, vsh.w, vmu.w, vis.w, vdb.w, vdg.w, lk) : 0.f;
+                    *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * p) * LDT + col4]) = v;
+                }
+            } else {
 #pragma unroll
             for (int p = 0; p < 4; ++p)
                 *reinterpret_cast<u32x4*>(&As[buf][((tid >> 3) + 32 * p) * LDT + col4]) = ra[p];
+            }
 #pragma unroll
             for (int p = 0; p < BL; ++p)
                 *reinterpret_cast<u32x4*>(&Bs[buf][((tid >> 3) + 32 * p) * LDT + col4]) = rb[p];
@@ -727,10 +759,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel_dma(const FvConvArgs a) {
     }
 }
 
-template <int BN, int WM_, int WN_, bool G>
+template <int BN, int WM_, int WN_, bool G, bool V = false>
 int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
     const int MT = (a.M + BM - 1) / BM, NT = (a.Nout + BN - 1) / BN;
     dim3 grid(MT * NT, a.ksplit > 1 ? a.ksplit : 1, a.nclass);
+    // (the BN-backward-applying instantiations are timed under the same names: same tiles, same role in the step)
     static const char* name = BN == 128 ? (G ? "conv_kernel<128,2,2,true>" : "conv_kernel<128,2,2,false>")
                               : BN == 64 ? (G ? "conv_kernel<64,2,2,true>" : "conv_kernel<64,2,2,false>")
                                          : (G ? "conv_kernel<32,4,1,true>" : "conv_kernel<32,4,1,false>");
@@ -740,7 +773,7 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
     FvConvArgs b = a;
     if (b.ksplit < 1) b.ksplit = 1;
     b.tail_f = 1; b.tail_full = 0; b.tail_slab = nullptr;
-    if constexpr (!G) {
+    if constexpr (!G && !V) {
         if (ctx->conv_dma) {   // measured neutral against the register-staged kernel; opt-in
             hipLaunchKernelGGL((conv_kernel_dma<BN, WM_, WN_>), grid, dim3(256), 0, ctx->stream, b);
             FV_LAUNCH_CHECK(ctx);
@@ -755,7 +788,7 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
             if (tf > 1 && need <= ctx->tail_slab_floats) {
                 b.tail_f = tf; b.tail_full = full; b.tail_slab = ctx->tail_slab;
                 const int R = MT * NT - full;
-                hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G>), dim3(full + R * tf, 1, 1), dim3(256), 0, ctx->stream, b);
+                hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G, V>), dim3(full + R * tf, 1, 1), dim3(256), 0, ctx->stream, b);
                 FV_LAUNCH_CHECK(ctx);
                 hipLaunchKernelGGL((conv_tail_fixup_kernel<BN>), dim3(R), dim3(1024), 0, ctx->stream, b);
                 FV_LAUNCH_CHECK(ctx);
@@ -763,7 +796,7 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
             }
         }
     }
-    hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G>), grid, dim3(256), 0, ctx->stream, b);
+    hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G, V>), grid, dim3(256), 0, ctx->stream, b);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }
@@ -808,6 +841,8 @@ void fv_conv_tail_plan(int M, int Nout, int ksteps, int* tail_f, int* tail_full,
     }
 }
 
+static inline bool gather_cin(int cin) { return cin % BK != 0; }
+
 int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
     FV_REQUIRE(ctx, a.x && a.w && a.out, "conv: NULL tensor");
     FV_REQUIRE(ctx, a.M > 0 && a.Nout > 0 && a.nclass >= 1 && a.nclass <= 4, "conv: bad problem size");
@@ -818,6 +853,7 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
     FV_REQUIRE(ctx, !(a.epi & FV_EPI_STATS) || (((a.psum && a.psq) || (a.stat_slots && a.stat_nslot >= 1)) && a.nclass == 1),
                "conv: stats need psum/psq or accumulator slots");
     FV_REQUIRE(ctx, !(a.epi & FV_EPI_ADD) || a.addend, "conv: FV_EPI_ADD needs addend");
+    FV_REQUIRE(ctx, !gather_cin(a.Cin) || !a.virt.z, "conv: the gathered first layer takes no BN-backward operand");
     FV_REQUIRE(ctx, !(a.epi & FV_EPI_BNRED) || (a.bn_z && a.bn_scale && a.bn_shift && a.bn_mean && a.bn_invstd && a.bn_slots &&
                                                  a.bn_nslot >= 1 && (a.Nout & 3) == 0 && a.ksplit <= 1 && !ctx->conv_dma &&
                                                  !(a.epi & (FV_EPI_STATS | FV_EPI_AFFINE | FV_EPI_LEAKY))),
@@ -835,6 +871,13 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
     }
     for (int c = 0; c < a.nclass; ++c)
         FV_REQUIRE(ctx, a.taps[c].n >= 1 && a.taps[c].n <= 9, "conv: bad tap count");
+    if (a.virt.z) {
+        FV_REQUIRE(ctx, a.virt.scale && a.virt.shift && a.virt.mean && a.virt.invstd && a.virt.dbm && a.virt.dgm && !ctx->conv_dma,
+                   "conv: the BN-backward operand needs its six per-channel vectors (and the register-staged kernel)");
+        if (a.Nout > 64) return launch_cfg<128, 2, 2, false, true>(ctx, a);
+        if (a.Nout > 32) return launch_cfg<64, 2, 2, false, true>(ctx, a);
+        return launch_cfg<32, 4, 1, false, true>(ctx, a);
+    }
     if (a.Nout > 64) return launch_cfg<128, 2, 2, false>(ctx, a);
     if (a.Nout > 32) return launch_cfg<64, 2, 2, false>(ctx, a);
     return launch_cfg<32, 4, 1, false>(ctx, a);

@@ -68,11 +68,11 @@ struct Carver {
 
 struct Plan {
     int B, S, nl;
-    std::vector<float*> z, a, mean, invstd, scale, shift, wt;
+    std::vector<float*> z, a, mean, invstd, scale, shift, wt, dbm, dgm;
     std::vector<double*> slots, bslots;   // per layer [nslot][2][cout] fp64 accumulators, forward statistics and
                                           // backward d-beta/d-gamma (one contiguous range over all layers)
     size_t slots_bytes;
-    float *w0p, *yhat, *dyp, *G[3], *D[2], *loss, *slab, *tail, *mse_part, *head_slab;
+    float *w0p, *yhat, *dyp, *G[5], *loss, *slab, *tail, *mse_part, *head_slab;
     int head_ks;
     size_t tail_floats;
     size_t bytes;
@@ -97,6 +97,7 @@ Plan make_plan(void* base, int B, int S, bool training) {
     Carver c(base);
     const int nb = p.nl - 1;
     p.z.resize(nb); p.a.resize(nb); p.mean.resize(nb); p.invstd.resize(nb); p.scale.resize(nb); p.shift.resize(nb);
+    p.dbm.resize(nb); p.dgm.resize(nb);
     p.wt.resize(p.nl);
     p.slots.resize(nb); p.bslots.resize(nb);
     size_t max_act = 0;
@@ -113,7 +114,7 @@ Plan make_plan(void* base, int B, int S, bool training) {
             const auto& d = N.L[l];
             p.scale[l] = sc_all ? sc_all + d.mean_off / 2 : nullptr;
             p.shift[l] = sh_all ? sh_all + d.mean_off / 2 : nullptr;
-            if (training) { p.mean[l] = c.take(d.cout); p.invstd[l] = c.take(d.cout); }
+            if (training) { p.mean[l] = c.take(d.cout); p.invstd[l] = c.take(d.cout); p.dbm[l] = c.take(d.cout); p.dgm[l] = c.take(d.cout); }
         }
     }
     p.w0p = c.take(32 * 32);
@@ -143,8 +144,9 @@ Plan make_plan(void* base, int B, int S, bool training) {
             }
         }
         p.dyp = c.take((size_t)B * G * G * HEAD_PAD);
-        for (int i = 0; i < 2; ++i) p.G[i] = c.take(max_act);   // activation gradients (ping-pong + kept block gradient)
-        for (int i = 0; i < 2; ++i) p.D[i] = c.take(max_act);   // dz of layer l lives in D[l&1] until its wgrad has run
+        // activation gradients g(l) = dL/d a(l): the one being consumed, the one being produced, the kept block gradient of a
+        // residual pair, and up to two more that a weight-gradient kernel on the side stream is still reading
+        for (int i = 0; i < 5; ++i) p.G[i] = c.take(max_act);
         p.loss = c.take(64);
         p.mse_part = c.take(fv_ew_mse_scratch_floats());
         // the head conv has 6 output channels: 53 tiles of 288 K steps -- K-split it like the batch-1 inference path
@@ -349,68 +351,68 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
     // ---------------- backward
     if (int rc = fv_op_conv_wgrad(ctx, p.a[nb - 1], p.dyp, batch, G, G, h.cin, h.cout, HEAD_PAD, 3, 1, grads + h.w_off)) return rc;
     // every data-gradient also reduces d-beta / d-gamma of the layer whose output gradient it produces (conv.h
-    // FV_EPI_BNRED): the BN-backward of that layer then is the apply pass alone
-    // (measured for every layer, also the 32/64-channel ones: fusing all of them 59.4 ms per step, none 61.0)
+    // FV_EPI_BNRED), and every consumer of dz(l) -- the weight-gradient and the data-gradient of layer l -- forms
+    // dz(l) from g(l) and z(l) while it stages its operand (conv.h FvVirtDz): BatchNorm's backward has no pass of its own,
+    // only bn_bwd_coeff (one small workgroup per layer: slot sums -> d-beta, d-gamma and the two per-channel vectors)
     auto bnred = [&](int l, FvBnRed& b) -> const FvBnRed* {
         const auto& d = N.L[l];
         b = FvBnRed{p.z[l], p.scale[l], p.shift[l], p.mean[l], p.invstd[l], p.bslots[l], fv_ew_bn_stat_slots(d.cout), LEAKY};
         return &b;
     };
     FvBnRed bnr;
-    bool reduced = bnred(nb - 1, bnr) != nullptr;
-    if (int rc = fv_op_conv_dgrad(ctx, p.dyp, p.wt[nb], batch, G, G, h.cin, HEAD_PAD, 3, 1, nullptr, p.G[0], reduced ? &bnr : nullptr)) return rc;
+    if (int rc = fv_op_conv_dgrad(ctx, p.dyp, p.wt[nb], batch, G, G, h.cin, HEAD_PAD, 3, 1, nullptr, p.G[0], bnred(nb - 1, bnr))) return rc;
     if (on_bucket) on_bucket(user, h.w_off, (int64_t)HEAD_C * 9 * 1024 + HEAD_C);
-    // G[ig]: gradient w.r.t. the current layer's (post-add) output; G[ires]: kept block gradient.
-    // dz(l) -> D[l&1].  The weight-gradient of layer l only needs dz(l) and the saved forward
-    // activation, so it runs on the side stream while this stream continues with dgrad(l) and
-    // bn_bwd(l-1); D[l&1] is reused by layer l-2 only after wgrad(l) has signalled ev_wg[l&1], which is
-    // also when the layer's gradient range is handed to the bucket callback.
+    // G[gcur]: g of the current layer; G[kept]: block gradient kept for the residual add; busy[par]: the buffer the
+    // weight-gradient of the last layer of that parity (side stream) may still be reading -- free again once ev_wg[par]
+    // has been waited for, which is also when that layer's gradient range is handed to the bucket callback.
     const bool ov = ctx->overlap && ctx->side;
     hipStream_t main_stream = ctx->stream;
     struct Pending { bool on; int64_t off, cnt; } pend[2] = {{false, 0, 0}, {false, 0, 0}};
+    int busy[2] = {-1, -1};
     auto join = [&](int par) -> int {
         if (!pend[par].on) return FV_OK;
         FV_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_wg[par], 0));
         if (on_bucket) on_bucket(user, pend[par].off, pend[par].cnt);
         pend[par].on = false;
+        busy[par] = -1;
         return FV_OK;
     };
-    int ig = 0, ires = -1;
+    int gcur = 0, kept = -1;
     for (int l = nb - 1; l >= 0; --l) {
         const auto& d = N.L[l];
         const int H = S / d.in_div, Ho = S / d.out_div;
         const long long rows = (long long)batch * Ho * Ho;
         const int par = l & 1;
         if (int rc = join(par)) return rc;
-        float* dz = p.D[par];
-        if (d.role == 2) ires = ig;  // add(skip, x): the same gradient also reaches the skip input
-        if (int rc = fv_ew_bn_bwd(ctx, p.G[ig], p.z[l], p.scale[l], p.shift[l], p.mean[l], p.invstd[l], rows, d.cout, LEAKY,
-                                  nullptr, nullptr, grads + d.beta_off, grads + d.gamma_off, dz, p.bslots[l], fv_ew_bn_stat_slots(d.cout),
-                                  reduced)) return rc;
+        if (d.role == 2) kept = gcur;  // add(skip, x): the same gradient also reaches the skip input
+        if (int rc = fv_ew_bn_bwd_coeff(ctx, p.bslots[l], fv_ew_bn_stat_slots(d.cout), rows, d.cout, grads + d.beta_off, grads + d.gamma_off,
+                                        p.dbm[l], p.dgm[l])) return rc;
+        const FvVirtDz vz{p.z[l], p.scale[l], p.shift[l], p.mean[l], p.invstd[l], p.dbm[l], p.dgm[l], LEAKY};
         const float* xin = l == 0 ? x : p.a[l - 1];
         const int64_t cnt = (int64_t)d.cout * d.ksize * d.ksize * d.cin + 2 * d.cout;
         if (ov) {
             FV_HIP(ctx, hipEventRecord(ctx->ev_dz[par], main_stream));
             FV_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_dz[par], 0));
             ctx->stream = ctx->side;
-            int rc = fv_op_conv_wgrad(ctx, xin, dz, batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off);
+            int rc = fv_op_conv_wgrad(ctx, xin, p.G[gcur], batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off, &vz);
             ctx->stream = main_stream;
             if (rc) return rc;
             FV_HIP(ctx, hipEventRecord(ctx->ev_wg[par], ctx->side));
             pend[par] = Pending{true, d.w_off, cnt};
+            busy[par] = gcur;
         } else {
-            if (int rc = fv_op_conv_wgrad(ctx, xin, dz, batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off)) return rc;
+            if (int rc = fv_op_conv_wgrad(ctx, xin, p.G[gcur], batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off, &vz)) return rc;
             if (on_bucket) on_bucket(user, d.w_off, cnt);
         }
         if (l == 0) break;
-        // dgrad overwrites the consumed gradient buffer G[ig] unless that is the kept block gradient
-        const int iout = (ig == ires) ? 1 - ig : ig;
-        const float* addend = d.role == 1 ? p.G[ires] : nullptr;
-        reduced = bnred(l - 1, bnr) != nullptr;
-        if (int rc = fv_op_conv_dgrad(ctx, dz, p.wt[l], batch, H, H, d.cin, d.cout, d.ksize, d.stride, addend, p.G[iout],
-                                      reduced ? &bnr : nullptr)) return rc;
-        ig = iout;
-        if (d.role == 1) ires = -1;
+        // the data-gradient reads G[gcur] through every tap while it writes g(l-1): another buffer, and not one that is kept or busy
+        int out = 0;
+        while (out == gcur || out == kept || out == busy[0] || out == busy[1]) ++out;
+        const float* addend = d.role == 1 ? p.G[kept] : nullptr;
+        if (int rc = fv_op_conv_dgrad(ctx, p.G[gcur], p.wt[l], batch, H, H, d.cin, d.cout, d.ksize, d.stride, addend, p.G[out],
+                                      bnred(l - 1, bnr), &vz)) return rc;
+        gcur = out;
+        if (d.role == 1) kept = -1;
     }
     if (int rc = join(1)) return rc;   // layer 1, then layer 0: ranges stay in descending order
     if (int rc = join(0)) return rc;

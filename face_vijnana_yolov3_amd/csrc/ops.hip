@@ -31,12 +31,13 @@ int fv_op_conv_forward(fv_ctx* ctx, const float* x, const float* w, int B, int H
 }
 
 int fv_op_conv_dgrad(fv_ctx* ctx, const float* dy, const float* w_t, int B, int H, int W, int cin, int cout_pad, int ksize,
-                     int stride, const float* addend, float* dx, const FvBnRed* bn) {
+                     int stride, const float* addend, float* dx, const FvBnRed* bn, const FvVirtDz* virt) {
     FV_REQUIRE(ctx, (ksize == 1 && stride == 1) || (ksize == 3 && (stride == 1 || stride == 2)), "dgrad: unsupported k=%d s=%d", ksize, stride);
     FV_REQUIRE(ctx, cout_pad % 32 == 0, "dgrad: cout_pad must be a multiple of 32");
     FV_REQUIRE(ctx, H % stride == 0 && W % stride == 0, "dgrad: H,W must be divisible by the stride");
     FvConvArgs a{};
     a.x = dy; a.w = w_t; a.out = dx; a.addend = addend;
+    if (virt) a.virt = *virt;
     a.B = B; a.Hin = H / stride; a.Win = W / stride; a.Cin = cout_pad;
     a.Hout = H; a.Wout = W; a.Nout = cin;
     a.is = 1; a.Tw = ksize * ksize;
@@ -85,10 +86,11 @@ int fv_op_conv_dgrad(fv_ctx* ctx, const float* dy, const float* w_t, int B, int 
 }
 
 int fv_op_conv_wgrad(fv_ctx* ctx, const float* x, const float* dy, int B, int H, int W, int cin, int cout, int dy_stride,
-                     int ksize, int stride, float* dw) {
+                     int ksize, int stride, float* dw, const FvVirtDz* virt) {
     FV_REQUIRE(ctx, (ksize == 1 && stride == 1) || (ksize == 3 && (stride == 1 || stride == 2)), "wgrad: unsupported k=%d s=%d", ksize, stride);
     FvWgradArgs a{};
     a.x = x; a.dy = dy; a.dw = dw;
+    if (virt) a.virt = *virt;
     a.B = B; a.Hin = H; a.Win = W; a.Cin = cin;
     a.Hl = H / stride; a.Wl = W / stride; a.N = cout; a.Ndy = dy_stride;
     a.is = stride; a.Tw = ksize * ksize; a.M = B * a.Hl * a.Wl;

@@ -23,7 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KP = 32;  // pixels per chunk
 
-template <int TM, int TN, bool QUAD, bool GATHER>
+template <int TM, int TN, bool QUAD, bool GATHER, bool VIRT = false>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int nsplit, int ntap_eff, int tiles_taps, int pinned) {
     constexpr int LDA = TM + 4, LDB = TN + 4;  // +4 keeps 16-byte row alignment for the staged float4 writes
     constexpr int WTM = QUAD ? TM / 2 : TM, WTN = QUAD ? TN / 2 : TN;
@@ -99,6 +99,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
         }
     }
     u32x4 ra[AL], rb[BL];
+    // VIRT: dy is g; the matching z rows are loaded beside it and the staged value is dz (conv.h FvVirtDz).  A thread keeps its
+    // four output channels over the whole pixel loop ((tid + 256 p) % (TM / 4) does not depend on p): six vectors, loaded once
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(VIRT ? a.virt.z : a.dy), 0, (int)((unsigned)a.M * a.Ndy * 4u), 0x00020000);
+    u32x4 rz[VIRT ? AL : 1];
+    bool st_ok[AL];
+    float4 vsc, vsh, vmu, vis, vdb, vdg;
+    if constexpr (VIRT) {
+        const int n = n0 + (tid % (TM / 4)) * 4;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool nv = n < a.N;
+        vsc = nv ? *reinterpret_cast<const float4*>(a.virt.scale + n) : zero; vsh = nv ? *reinterpret_cast<const float4*>(a.virt.shift + n) : zero;
+        vmu = nv ? *reinterpret_cast<const float4*>(a.virt.mean + n) : zero; vis = nv ? *reinterpret_cast<const float4*>(a.virt.invstd + n) : zero;
+        vdb = nv ? *reinterpret_cast<const float4*>(a.virt.dbm + n) : zero; vdg = nv ? *reinterpret_cast<const float4*>(a.virt.dgm + n) : zero;
+    }
 #if defined(FV_ABLATE_NOLOAD)
     for (int p = 0; p < AL; ++p) ra[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
     for (int p = 0; p < BL; ++p) rb[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
@@ -115,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
             off = a_off[p] != OOB ? (unsigned)(tid / (TM / 4)) * (unsigned)a.Ndy * 4u + a_off[p] : OOB;
 #endif
             ra[p] = __builtin_amdgcn_raw_buffer_load_b128(yr, off, 0, 0);
+            if constexpr (VIRT) { rz[p] = __builtin_amdgcn_raw_buffer_load_b128(zr, off, 0, 0); st_ok[p] = a_m[p] < a.M && a_off[p] != OOB; }
             a_m[p] += KP;
         }
         if constexpr (GATHER) {
@@ -158,7 +174,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
 #pragma unroll
         for (int p = 0; p < AL; ++p) {
             int f = tid + 256 * p, row = f / (TM / 4), col = (f % (TM / 4)) * 4;
-            *reinterpret_cast<u32x4*>(&As[buf][row * LDA + col]) = ra[p];
+            if constexpr (VIRT) {
+                const float lk = a.virt.leaky;
+                const bool ok = st_ok[p];
+                float4 v;
+                v.x = ok ? fv_virt_dz1(__uint_as_float(ra[p].x), __uint_as_float(rz[p].x), vsc.x, vsh.x, vmu.x, vis.x, vdb.x, vdg.x, lk) : 0.f;
+                v.y = ok ? fv_virt_dz1(__uint_as_float(ra[p].y), __uint_as_float(rz[p].y), vsc.y, vsh.y, vmu.y, vis.y, vdb.y, vdg.y, lk) : 0.f;
+                v.z = ok ? fv_virt_dz1(__uint_as_float(ra[p].z), __uint_as_float(rz[p].z), vsc.z, vsh.z, vmu.z, vis.z, vdb.z, vdg.z, lk) : 0.f;
+                v.w = ok ? fv_virt_dz1(__uint_as_float(ra[p].w), __uint_as_float(rz[p].w), vsc.w, vsh.w, vmu.w, vis.w, vdb.w, vdg.w, lk) : 0.f;
+                *reinterpret_cast<float4*>(&As[buf][row * LDA + col]) = v;
+            } else {
+                *reinterpret_cast<u32x4*>(&As[buf][row * LDA + col]) = ra[p];
+            }
         }
         if constexpr (GATHER) {
             *reinterpret_cast<u32x4*>(&Bs[buf][(tid >> 3) * LDB + (tid & 7) * 4]) = rb[0];
@@ -237,6 +264,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
 
 template <int TM, int TN, bool QUAD, bool GATHER>
 int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
+    if (a.virt.z)
+        FV_REQUIRE(ctx, a.virt.scale && a.virt.shift && a.virt.mean && a.virt.invstd && a.virt.dbm && a.virt.dgm && a.N % 4 == 0,
+                   "wgrad: the BN-backward operand needs its six per-channel vectors and N %% 4 == 0");
     const int ntap = GATHER ? 1 : a.taps.n;
     const int tiles = ((a.N + TM - 1) / TM) * (GATHER ? 1 : a.Cin / TN) * ntap;
     const int total_chunks = (a.M + KP - 1) / KP;
@@ -268,7 +298,10 @@ int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
     FvProfScope ps(ctx, name, a.alg_flops,
                    4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.M * a.N + (double)a.N * a.Tw * a.Cin));
     const int nsplit8 = pinned ? (nsplit + 7) / 8 * 8 : nsplit;   // padded splits return at once (no chunks)
-    hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER>), dim3(tiles * nsplit8), dim3(256), 0, ctx->stream, a, nsplit, ntap, tiles, pinned);
+    if (a.virt.z)
+        hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER, true>), dim3(tiles * nsplit8), dim3(256), 0, ctx->stream, a, nsplit, ntap, tiles, pinned);
+    else
+        hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER>), dim3(tiles * nsplit8), dim3(256), 0, ctx->stream, a, nsplit, ntap, tiles, pinned);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }

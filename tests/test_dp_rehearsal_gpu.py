@@ -115,7 +115,7 @@ def test_two_ranks_match_the_merged_batch_oracle(tmp_path):
             n64 = g64[sl].norm().item()
             rel = (got[sl] - g64[sl]).norm().item() / max(n64, 1e-30)
             rel32 = (g32[sl] - g64[sl]).norm().item() / max(n64, 1e-30)
-            assert rel <= max(6 * rel32, 2e-5), (e['name'], rel, rel32)
+            assert rel <= max(6 * rel32, 4e-5), (e['name'], rel, rel32)
             worst = max(worst, rel)
     # a plain mean of the two slice gradients (what equal weights would give) is far outside that bound
     hd = slice(ents[-1]['w_off'], ents[-1]['w_off'] + 6 * 9 * 1024)
