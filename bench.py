@@ -54,6 +54,7 @@ def parse():
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-overlap', action='store_true', help='serialise wgrad on the main stream (A/B aid)')
     ap.add_argument('--no-tail-split', action='store_true', help='conv launches without the tail split (A/B aid)')
+    ap.add_argument('--fused-bn-backward', action='store_true', help='fv_set_fused_bn_backward(1) (A/B aid; measured slower)')
     ap.add_argument('--no-detect', action='store_true', help='skip the detect-path measurement (PMC passes)')
     ap.add_argument('--no-loader', action='store_true', help='skip the loader-inclusive measurement')
     ap.add_argument('--loader-steps', type=int, default=6)
@@ -263,6 +264,8 @@ def main():
         eng.ctx.set_overlap(False)
     if args.no_tail_split:
         eng.ctx.set_tail_split(False)
+    if args.fused_bn_backward:
+        eng.ctx.set_fused_bn_backward(True)
     trainer = DataParallelTrainer(eng, world_size=world, rank=rank)  # inits RCCL when world > 1
     B, S = args.batch, args.image_size
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)

@@ -65,8 +65,10 @@ def _declare(L):
         'fv_set_conv_dma': (i32, [vp, i32]),
         'fv_set_tail_split': (i32, [vp, i32]),
         'fv_set_conv_scratch': (i32, [vp, vp, sz]),
+        'fv_set_fused_bn_backward': (i32, [vp, i32]),
         'fv_profile_enable': (i32, [vp, i32]),
         'fv_profile_collect': (i32, [vp, ctypes.POINTER(ProfileRec), i32, ctypes.POINTER(i32)]),
+        'fv_bbox_iou_pairs': (i32, [vp, vp, vp, i64, vp]),
         'fv_num_layers': (i32, []),
         'fv_layer': (i32, [i32, ctypes.POINTER(LayerDesc)]),
         'fv_param_count': (i64, []),
@@ -91,6 +93,9 @@ def _declare(L):
         'fv_bn_act_slots': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, f32]),
         'fv_conv2d_dgrad_bnred': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, i32]),
         'fv_bn_bwd_slots': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp, i32, i32, vp, vp, vp]),
+        'fv_bn_bwd_coeff': (i32, [vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, vp, vp]),
+        'fv_conv2d_dgrad_fused': (i32, [vp, vp, vp, vp, f32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
+        'fv_conv2d_wgrad_fused': (i32, [vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, i32, i32, vp]),
         'fv_mse_loss_grad': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
         'fv_fd_loss_grad': (i32, [vp, vp, vp, i32, i32, vp, vp]),
         'fv_letterbox': (i32, [vp, vp, i32, i32, i32, vp, ctypes.POINTER(ctypes.c_int32)]),
@@ -146,6 +151,9 @@ class Context:
 
     def set_tail_split(self, on):
         self.check(lib().fv_set_tail_split(self._h, 1 if on else 0), 'fv_set_tail_split')
+
+    def set_fused_bn_backward(self, on):
+        self.check(lib().fv_set_fused_bn_backward(self._h, 1 if on else 0), 'fv_set_fused_bn_backward')
 
     def set_conv_scratch(self, tensor):
         """Lend device scratch (a torch tensor, kept alive here) to the per-operator conv calls."""

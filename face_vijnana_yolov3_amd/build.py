@@ -15,7 +15,7 @@ CSRC = os.path.join(PKG, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libfv_hotpath.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wall',
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-fno-slp-vectorize', '-Wall',
          '-Wno-unused-function', '-Wno-unused-variable']
 
 

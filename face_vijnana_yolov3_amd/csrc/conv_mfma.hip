@@ -241,8 +241,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
         const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(VIRT ? a.virt.z : a.x), 0, (int)((unsigned)a.B * a.Hin * a.Win * a.Cin * 4u), 0x00020000);
         u32x4 rz[VIRT ? 4 : 1];
-        float4 vsc, vsh, vmu, vis, vdb, vdg;
-        unsigned st_off[4];   // a_off of the loaded (not yet staged) step: advance() may move a_off before stage()
+        FvVirtVec vv;
+        float4 tv[VIRT ? 4 : 1];   // transformed rows, formed between the MFMAs of chunks 1-2, written to LDS by stage()
+        unsigned st_off[4];        // a_off of the loaded step
         unsigned a_off[4];
         int t = s_begin / cpk, ci = s_begin - t * cpk;
         auto set_tap = [&](int tp) {
@@ -270,29 +271,28 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
             if constexpr (VIRT) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) { rz[p] = __builtin_amdgcn_raw_buffer_load_b128(zr, a_off[p], c0b, 0); st_off[p] = a_off[p]; }
-                const int kc = ci * BK + col4;
-                vsc = *reinterpret_cast<const float4*>(a.virt.scale + kc); vsh = *reinterpret_cast<const float4*>(a.virt.shift + kc);
-                vmu = *reinterpret_cast<const float4*>(a.virt.mean + kc); vis = *reinterpret_cast<const float4*>(a.virt.invstd + kc);
-                vdb = *reinterpret_cast<const float4*>(a.virt.dbm + kc); vdg = *reinterpret_cast<const float4*>(a.virt.dgm + kc);
+                vv = fv_virt_load(a.virt.tab, ci * BK + col4);
             }
 #pragma unroll
             for (int p = 0; p < BL; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_row[p], wofs, 0);
         };
+        auto transform = [&](int p) {   // VIRT only: row p of the loaded step -> tv[p]
+            if constexpr (VIRT) {
+                const float4 g = make_float4(__uint_as_float(ra[p].x), __uint_as_float(ra[p].y), __uint_as_float(ra[p].z), __uint_as_float(ra[p].w));
+                const float4 z = make_float4(__uint_as_float(rz[p].x), __uint_as_float(rz[p].y), __uint_as_float(rz[p].z), __uint_as_float(rz[p].w));
+                tv[p] = fv_virt_dz4(g, z, vv, a.virt.leaky, st_off[p] != OOB);
+            }
+        };
+        // pins tv[p] as computed HERE: without it the compiler sinks the whole transform into the `if (more)` block of stage(),
+        // behind the MFMAs it is meant to hide under
+        auto pin = [&](int p) {
+            if constexpr (VIRT) asm volatile("" : "+v"(tv[p].x), "+v"(tv[p].y), "+v"(tv[p].z), "+v"(tv[p].w));
+        };
         auto stage = [&](int buf) {
             if constexpr (VIRT) {
-                const float lk = a.virt.leaky;
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const bool ok = st_off[p] != OOB;
-                    const float g0 = __uint_as_float(ra[p].x), g1 = __uint_as_float(ra[p].y), g2 = __uint_as_float(ra[p].z), g3 = __uint_as_float(ra[p].w);
-                    const float z0 = __uint_as_float(rz[p].x), z1 = __uint_as_float(rz[p].y), z2 = __uint_as_float(rz[p].z), z3 = __uint_as_float(rz[p].w);
-                    float4 v;
-                    v.x = ok ? fv_virt_dz1(g0, z0, vsc.x, vsh.x, vmu.x, vis.x, vdb.x, vdg.x, lk) : 0.f;
-                    v.y = ok ? fv_virt_dz1(g1, z1, vsc.y, vsh.y, vmu.y, vis.y, vdb.y, vdg.y, lk) : 0.f;
-                    v.z = ok ? fv_virt_dz1(g2, z2, vsc.z, vsh.z, vmu.z, vis.z, vdb.z, vdg.z, lk) : 0.f;
-                    v.w = ok ? fv_virt_dz1(g3, z3, vsc.w, vsh.w, vmu.w, vis.w, vdb.w, vdg.w, lk) : 0.f;
-                    *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * p) * LDT + col4]) = v;
-                }
+                for (int p = 0; p < 4; ++p)
+                    *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * p) * LDT + col4]) = tv[p];
             } else {
 #pragma unroll
             for (int p = 0; p < 4; ++p)
@@ -337,6 +337,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
         if (s_begin < s_end) {
             set_tap(t);
             load();
+#pragma unroll
+            for (int p = 0; p < 4; ++p) transform(p);
             stage(0);
             advance();
         }
@@ -357,10 +359,30 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
             readfrag(As[cur], Bs[cur], 2, af0, bf0);
             __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(af1, bf1);
+            if constexpr (VIRT) {
+                // the operand transform rides in the issue gaps of these MFMAs (64 cycles each, 8 of them blocking the vector
+                // issue): one MFMA, then a handful of its VALU instructions, and so on -- placed as a block it costs the step 18 %
+                transform(0); transform(1);   // unconditional (one basic block with the MFMAs); unused after the last K step
+#pragma unroll
+                for (int i = 0; i < MB * NB * 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                }
+                pin(0); pin(1);
+            }
             __builtin_amdgcn_sched_barrier(0);
             readfrag(As[cur], Bs[cur], 3, af1, bf1);
             __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(af0, bf0);
+            if constexpr (VIRT) {
+                transform(2); transform(3);
+#pragma unroll
+                for (int i = 0; i < MB * NB * 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                }
+                pin(2); pin(3);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (more) { stage(cur ^ 1); advance(); }
             __builtin_amdgcn_sched_barrier(0);
@@ -872,8 +894,7 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
     for (int c = 0; c < a.nclass; ++c)
         FV_REQUIRE(ctx, a.taps[c].n >= 1 && a.taps[c].n <= 9, "conv: bad tap count");
     if (a.virt.z) {
-        FV_REQUIRE(ctx, a.virt.scale && a.virt.shift && a.virt.mean && a.virt.invstd && a.virt.dbm && a.virt.dgm && !ctx->conv_dma,
-                   "conv: the BN-backward operand needs its six per-channel vectors (and the register-staged kernel)");
+        FV_REQUIRE(ctx, a.virt.tab && !ctx->conv_dma, "conv: the BN-backward operand needs its per-channel table (and the register-staged kernel)");
         if (a.Nout > 64) return launch_cfg<128, 2, 2, false, true>(ctx, a);
         if (a.Nout > 32) return launch_cfg<64, 2, 2, false, true>(ctx, a);
         return launch_cfg<32, 4, 1, false, true>(ctx, a);

@@ -322,17 +322,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_slots_kernel(const float4* _
     }
 }
 
-// The slot sums alone, for the fused backward (conv.h FvVirtDz): d-beta / d-gamma into the gradient vector and the two
-// per-channel vectors dbm = d-beta / rows, dgm = d-gamma / rows the operand-staging code of the consumer kernels needs -- the
-// same float values bn_bwd_apply_slots_kernel forms, so the fused and the separate path agree bit for bit.
+// The slot sums alone, for the fused backward (conv.h FvVirtDz): d-beta / d-gamma into the gradient vector, and the per-channel
+// table [C/4][6][4] = (scale, shift, mean, invstd, dbm = d-beta / rows, dgm = d-gamma / rows) the operand-staging code of the
+// consumer kernels reads -- the same float values bn_bwd_apply_slots_kernel forms, so the fused and the separate path agree
+// bit for bit.
 __global__ __launch_bounds__(256) void bn_bwd_coeff_kernel(const double* __restrict__ slots, int nslot, int C, float inv_count,
-                                                           float* __restrict__ dbeta, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbm, float* __restrict__ dgm) {
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           float* __restrict__ dbeta, float* __restrict__ dgamma, float* __restrict__ tab) {
     __shared__ double s_part[2][256];
     const int tid = threadIdx.x;
     auto finish = [&](int c, double a, double b) {
         const float db = (float)a, dg = (float)b;
-        dbeta[c] = db; dgamma[c] = dg; dbm[c] = db * inv_count; dgm[c] = dg * inv_count;
+        dbeta[c] = db; dgamma[c] = dg;
+        float* t = tab + (size_t)(c >> 2) * 24 + (c & 3);
+        t[0] = scale[c]; t[4] = shift[c]; t[8] = mean[c]; t[12] = invstd[c]; t[16] = db * inv_count; t[20] = dg * inv_count;
     };
     if (C >= 256) {
         const int c = blockIdx.x * 256 + tid;
@@ -664,11 +668,11 @@ int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale
     return FV_OK;
 }
 
-int fv_ew_bn_bwd_coeff(fv_ctx* ctx, const double* slots, int nslot, long long rows, int C, float* dbeta, float* dgamma, float* dbm,
-                       float* dgm) {
+int fv_ew_bn_bwd_coeff(fv_ctx* ctx, const double* slots, int nslot, long long rows, int C, const float* scale, const float* shift,
+                       const float* mean, const float* invstd, float* dbeta, float* dgamma, float* tab) {
     FV_REQUIRE(ctx, slots && nslot >= 1 && C % 4 == 0 && C <= 1024 && (C >= 256 || 256 % C == 0), "bn_bwd_coeff: bad slots / C");
     hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(C >= 256 ? (C + 255) / 256 : 1), dim3(256), 0, ctx->stream, slots, nslot, C,
-                       (float)(1.0 / (double)rows), dbeta, dgamma, dbm, dgm);
+                       (float)(1.0 / (double)rows), scale, shift, mean, invstd, dbeta, dgamma, tab);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }

@@ -68,7 +68,7 @@ struct Carver {
 
 struct Plan {
     int B, S, nl;
-    std::vector<float*> z, a, mean, invstd, scale, shift, wt, dbm, dgm;
+    std::vector<float*> z, a, mean, invstd, scale, shift, wt, vtab;
     std::vector<double*> slots, bslots;   // per layer [nslot][2][cout] fp64 accumulators, forward statistics and
                                           // backward d-beta/d-gamma (one contiguous range over all layers)
     size_t slots_bytes;
@@ -97,7 +97,7 @@ Plan make_plan(void* base, int B, int S, bool training) {
     Carver c(base);
     const int nb = p.nl - 1;
     p.z.resize(nb); p.a.resize(nb); p.mean.resize(nb); p.invstd.resize(nb); p.scale.resize(nb); p.shift.resize(nb);
-    p.dbm.resize(nb); p.dgm.resize(nb);
+    p.vtab.resize(nb);
     p.wt.resize(p.nl);
     p.slots.resize(nb); p.bslots.resize(nb);
     size_t max_act = 0;
@@ -114,7 +114,7 @@ Plan make_plan(void* base, int B, int S, bool training) {
             const auto& d = N.L[l];
             p.scale[l] = sc_all ? sc_all + d.mean_off / 2 : nullptr;
             p.shift[l] = sh_all ? sh_all + d.mean_off / 2 : nullptr;
-            if (training) { p.mean[l] = c.take(d.cout); p.invstd[l] = c.take(d.cout); p.dbm[l] = c.take(d.cout); p.dgm[l] = c.take(d.cout); }
+            if (training) { p.mean[l] = c.take(d.cout); p.invstd[l] = c.take(d.cout); p.vtab[l] = c.take(6 * (size_t)d.cout); }
         }
     }
     p.w0p = c.take(32 * 32);
@@ -351,9 +351,13 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
     // ---------------- backward
     if (int rc = fv_op_conv_wgrad(ctx, p.a[nb - 1], p.dyp, batch, G, G, h.cin, h.cout, HEAD_PAD, 3, 1, grads + h.w_off)) return rc;
     // every data-gradient also reduces d-beta / d-gamma of the layer whose output gradient it produces (conv.h
-    // FV_EPI_BNRED), and every consumer of dz(l) -- the weight-gradient and the data-gradient of layer l -- forms
-    // dz(l) from g(l) and z(l) while it stages its operand (conv.h FvVirtDz): BatchNorm's backward has no pass of its own,
-    // only bn_bwd_coeff (one small workgroup per layer: slot sums -> d-beta, d-gamma and the two per-channel vectors)
+    // FV_EPI_BNRED): the BN-backward of that layer then is the apply pass alone (measured for every layer, also the
+    // 32/64-channel ones: fusing all of them 59.4 ms per step, none 61.0).
+    // fv_set_fused_bn_backward(1) goes one step further: every consumer of dz(l) -- the weight-gradient and the
+    // data-gradient of layer l -- forms dz(l) from g(l) and z(l) while it stages its operand (conv.h FvVirtDz), and
+    // BatchNorm's backward has no pass of its own.  Bit-identical gradients, but MEASURED SLOWER on MI355X (63.7 against
+    // 58.7 ms per step: the apply pass costs 3.0 ms at 5.3 TB/s, the operand transform + second operand stream cost the
+    // matrix kernels 8 ms), so the separate pass stays the default.
     auto bnred = [&](int l, FvBnRed& b) -> const FvBnRed* {
         const auto& d = N.L[l];
         b = FvBnRed{p.z[l], p.scale[l], p.shift[l], p.mean[l], p.invstd[l], p.bslots[l], fv_ew_bn_stat_slots(d.cout), LEAKY};
@@ -377,6 +381,49 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
         busy[par] = -1;
         return FV_OK;
     };
+    if (!ctx->fused_bn_bwd) {
+    // G[ig]: gradient w.r.t. the current layer's (post-add) output; G[ires]: kept block gradient.
+    // dz(l) -> D[l&1].  The weight-gradient of layer l only needs dz(l) and the saved forward
+    // activation, so it runs on the side stream while this stream continues with dgrad(l) and
+    // bn_bwd(l-1); D[l&1] is reused by layer l-2 only after wgrad(l) has signalled ev_wg[l&1].
+    float* const D[2] = {p.G[2], p.G[3]};
+    int ig = 0, ires = -1;
+    for (int l = nb - 1; l >= 0; --l) {
+        const auto& d = N.L[l];
+        const int H = S / d.in_div, Ho = S / d.out_div;
+        const long long rows = (long long)batch * Ho * Ho;
+        const int par = l & 1;
+        if (int rc = join(par)) return rc;
+        float* dz = D[par];
+        if (d.role == 2) ires = ig;  // add(skip, x): the same gradient also reaches the skip input
+        if (int rc = fv_ew_bn_bwd(ctx, p.G[ig], p.z[l], p.scale[l], p.shift[l], p.mean[l], p.invstd[l], rows, d.cout, LEAKY,
+                                  nullptr, nullptr, grads + d.beta_off, grads + d.gamma_off, dz, p.bslots[l], fv_ew_bn_stat_slots(d.cout),
+                                  true)) return rc;
+        const float* xin = l == 0 ? x : p.a[l - 1];
+        const int64_t cnt = (int64_t)d.cout * d.ksize * d.ksize * d.cin + 2 * d.cout;
+        if (ov) {
+            FV_HIP(ctx, hipEventRecord(ctx->ev_dz[par], main_stream));
+            FV_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_dz[par], 0));
+            ctx->stream = ctx->side;
+            int rc = fv_op_conv_wgrad(ctx, xin, dz, batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off);
+            ctx->stream = main_stream;
+            if (rc) return rc;
+            FV_HIP(ctx, hipEventRecord(ctx->ev_wg[par], ctx->side));
+            pend[par] = Pending{true, d.w_off, cnt};
+        } else {
+            if (int rc = fv_op_conv_wgrad(ctx, xin, dz, batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off)) return rc;
+            if (on_bucket) on_bucket(user, d.w_off, cnt);
+        }
+        if (l == 0) break;
+        // dgrad overwrites the consumed gradient buffer G[ig] unless that is the kept block gradient
+        const int iout = (ig == ires) ? 1 - ig : ig;
+        const float* addend = d.role == 1 ? p.G[ires] : nullptr;
+        if (int rc = fv_op_conv_dgrad(ctx, dz, p.wt[l], batch, H, H, d.cin, d.cout, d.ksize, d.stride, addend, p.G[iout],
+                                      bnred(l - 1, bnr))) return rc;
+        ig = iout;
+        if (d.role == 1) ires = -1;
+    }
+    } else {
     int gcur = 0, kept = -1;
     for (int l = nb - 1; l >= 0; --l) {
         const auto& d = N.L[l];
@@ -385,9 +432,9 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
         const int par = l & 1;
         if (int rc = join(par)) return rc;
         if (d.role == 2) kept = gcur;  // add(skip, x): the same gradient also reaches the skip input
-        if (int rc = fv_ew_bn_bwd_coeff(ctx, p.bslots[l], fv_ew_bn_stat_slots(d.cout), rows, d.cout, grads + d.beta_off, grads + d.gamma_off,
-                                        p.dbm[l], p.dgm[l])) return rc;
-        const FvVirtDz vz{p.z[l], p.scale[l], p.shift[l], p.mean[l], p.invstd[l], p.dbm[l], p.dgm[l], LEAKY};
+        if (int rc = fv_ew_bn_bwd_coeff(ctx, p.bslots[l], fv_ew_bn_stat_slots(d.cout), rows, d.cout, p.scale[l], p.shift[l], p.mean[l],
+                                        p.invstd[l], grads + d.beta_off, grads + d.gamma_off, p.vtab[l])) return rc;
+        const FvVirtDz vz{p.z[l], p.vtab[l], LEAKY};
         const float* xin = l == 0 ? x : p.a[l - 1];
         const int64_t cnt = (int64_t)d.cout * d.ksize * d.ksize * d.cin + 2 * d.cout;
         if (ov) {
@@ -413,6 +460,7 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
                                       bnred(l - 1, bnr), &vz)) return rc;
         gcur = out;
         if (d.role == 1) kept = -1;
+    }
     }
     if (int rc = join(1)) return rc;   // layer 1, then layer 0: ranges stay in descending order
     if (int rc = join(0)) return rc;

@@ -211,6 +211,36 @@ int fv_bn_bwd_slots(fv_ctx* ctx, const float* g, const float* z, const float* sc
                         reduced != 0);
 }
 
+int fv_bn_bwd_coeff(fv_ctx* ctx, const double* slots, int nslot, int64_t rows, int C, const float* scale, const float* shift,
+                    const float* mean, const float* invstd, float* dbeta, float* dgamma, float* tab) {
+    if (!ctx) return FV_ERR_INVALID;
+    FV_REQUIRE(ctx, scale && shift && mean && invstd && dbeta && dgamma && tab && rows > 0, "bn_bwd_coeff: NULL buffer");
+    return fv_ew_bn_bwd_coeff(ctx, slots, nslot, rows, C, scale, shift, mean, invstd, dbeta, dgamma, tab);
+}
+
+int fv_conv2d_dgrad_fused(fv_ctx* ctx, const float* g, const float* z, const float* tab, float leaky, const float* w_t, int B, int H,
+                          int W, int cin, int cout_pad, int ksize, int stride, const float* addend, float* dx, const float* bn_z,
+                          const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_slots,
+                          int bn_nslot) {
+    if (!ctx) return FV_ERR_INVALID;
+    FV_REQUIRE(ctx, g && z && tab, "conv2d_dgrad_fused: NULL tensor");
+    const FvVirtDz vz{z, tab, leaky};
+    if (bn_z) {
+        if (int rc = slots_ok(ctx, bn_slots, bn_nslot, cin, "conv2d_dgrad_fused")) return rc;
+        FvBnRed b{bn_z, bn_scale, bn_shift, bn_mean, bn_invstd, bn_slots, bn_nslot, leaky};
+        return fv_op_conv_dgrad(ctx, g, w_t, B, H, W, cin, cout_pad, ksize, stride, addend, dx, &b, &vz);
+    }
+    return fv_op_conv_dgrad(ctx, g, w_t, B, H, W, cin, cout_pad, ksize, stride, addend, dx, nullptr, &vz);
+}
+
+int fv_conv2d_wgrad_fused(fv_ctx* ctx, const float* x, const float* g, const float* z, const float* tab, float leaky, int B, int H,
+                          int W, int cin, int cout, int ksize, int stride, float* dw) {
+    if (!ctx) return FV_ERR_INVALID;
+    FV_REQUIRE(ctx, g && z && tab, "conv2d_wgrad_fused: NULL tensor");
+    const FvVirtDz vz{z, tab, leaky};
+    return fv_op_conv_wgrad(ctx, x, g, B, H, W, cin, cout, cout, ksize, stride, dw, &vz);
+}
+
 int fv_mse_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int c_pad, float* loss, float* dy,
                      float* dbias) {
     if (!ctx) return FV_ERR_INVALID;

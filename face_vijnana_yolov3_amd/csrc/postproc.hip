@@ -207,3 +207,43 @@ extern "C" int fv_decode_nms(fv_ctx* ctx, const float* head, int nimg, int grid,
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Batched bbox_iou for the accuracy metric (reference evaluate.py:46-75 calls yd.py:183-194 bbox_iou on every
+// (ground truth, detection) pair of an image, with float64 corner coordinates read from the csv files): one thread per
+// pair, float64 arithmetic in the reference's operation order and branch structure -- every operation is a single IEEE
+// double operation, so the result is bit-identical to the Python floats.  A zero union gives nan (0/0) or +-inf, as NumPy does.
+namespace {
+__device__ __forceinline__ double interval_overlap_f64(double x1, double x2, double x3, double x4) {
+    if (x3 < x1) {
+        if (x4 < x1) return 0.0;
+        return fmin(x2, x4) - x1;
+    } else {
+        if (x2 < x3) return 0.0;
+        return fmin(x2, x4) - x3;
+    }
+}
+__global__ __launch_bounds__(256) void bbox_iou_pairs_kernel(const double* __restrict__ a, const double* __restrict__ b, long long n,
+                                                             double* __restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double ax0 = a[4 * i], ay0 = a[4 * i + 1], ax1 = a[4 * i + 2], ay1 = a[4 * i + 3];
+        const double bx0 = b[4 * i], by0 = b[4 * i + 1], bx1 = b[4 * i + 2], by1 = b[4 * i + 3];
+        const double iw = interval_overlap_f64(ax0, ax1, bx0, bx1), ih = interval_overlap_f64(ay0, ay1, by0, by1);
+        const double inter = iw * ih;
+        const double uni = (ax1 - ax0) * (ay1 - ay0) + (bx1 - bx0) * (by1 - by0) - inter;
+        out[i] = inter / uni;
+    }
+}
+}  // namespace
+
+extern "C" int fv_bbox_iou_pairs(fv_ctx* ctx, const double* boxes_a, const double* boxes_b, int64_t npairs, double* iou) {
+    if (!ctx) return FV_ERR_INVALID;
+    FV_REQUIRE(ctx, npairs >= 0 && (npairs == 0 || (boxes_a && boxes_b && iou)), "bbox_iou_pairs: NULL buffer");
+    if (npairs == 0) return FV_OK;
+    long long g = (npairs + 255) / 256;
+    hipLaunchKernelGGL(bbox_iou_pairs_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, ctx->stream, boxes_a, boxes_b,
+                       (long long)npairs, iou);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}

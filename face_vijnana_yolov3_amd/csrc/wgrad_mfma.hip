@@ -104,15 +104,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
     const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(VIRT ? a.virt.z : a.dy), 0, (int)((unsigned)a.M * a.Ndy * 4u), 0x00020000);
     u32x4 rz[VIRT ? AL : 1];
+    float4 tv[VIRT ? AL : 1];
     bool st_ok[AL];
-    float4 vsc, vsh, vmu, vis, vdb, vdg;
+    FvVirtVec vv;
     if constexpr (VIRT) {
         const int n = n0 + (tid % (TM / 4)) * 4;
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool nv = n < a.N;
-        vsc = nv ? *reinterpret_cast<const float4*>(a.virt.scale + n) : zero; vsh = nv ? *reinterpret_cast<const float4*>(a.virt.shift + n) : zero;
-        vmu = nv ? *reinterpret_cast<const float4*>(a.virt.mean + n) : zero; vis = nv ? *reinterpret_cast<const float4*>(a.virt.invstd + n) : zero;
-        vdb = nv ? *reinterpret_cast<const float4*>(a.virt.dbm + n) : zero; vdg = nv ? *reinterpret_cast<const float4*>(a.virt.dgm + n) : zero;
+        vv = fv_virt_load(a.virt.tab, n < a.N ? n : 0);     // channel groups outside N are masked by st_ok
     }
 #if defined(FV_ABLATE_NOLOAD)
     for (int p = 0; p < AL; ++p) ra[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
@@ -170,22 +167,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
             }
         }
     };
+    // VIRT: row p of the loaded chunk -> tv[p] (branch-free, placed between the MFMAs; conv.h FvVirtDz); pin() keeps it there
+    auto transform = [&](int p) {
+        if constexpr (VIRT) {
+            const float4 g = make_float4(__uint_as_float(ra[p].x), __uint_as_float(ra[p].y), __uint_as_float(ra[p].z), __uint_as_float(ra[p].w));
+            const float4 z = make_float4(__uint_as_float(rz[p].x), __uint_as_float(rz[p].y), __uint_as_float(rz[p].z), __uint_as_float(rz[p].w));
+            tv[p] = fv_virt_dz4(g, z, vv, a.virt.leaky, st_ok[p]);
+        }
+    };
+    auto pin = [&](int p) {
+        if constexpr (VIRT) asm volatile("" : "+v"(tv[p].x), "+v"(tv[p].y), "+v"(tv[p].z), "+v"(tv[p].w));
+    };
     auto stage = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < AL; ++p) {
             int f = tid + 256 * p, row = f / (TM / 4), col = (f % (TM / 4)) * 4;
-            if constexpr (VIRT) {
-                const float lk = a.virt.leaky;
-                const bool ok = st_ok[p];
-                float4 v;
-                v.x = ok ? fv_virt_dz1(__uint_as_float(ra[p].x), __uint_as_float(rz[p].x), vsc.x, vsh.x, vmu.x, vis.x, vdb.x, vdg.x, lk) : 0.f;
-                v.y = ok ? fv_virt_dz1(__uint_as_float(ra[p].y), __uint_as_float(rz[p].y), vsc.y, vsh.y, vmu.y, vis.y, vdb.y, vdg.y, lk) : 0.f;
-                v.z = ok ? fv_virt_dz1(__uint_as_float(ra[p].z), __uint_as_float(rz[p].z), vsc.z, vsh.z, vmu.z, vis.z, vdb.z, vdg.z, lk) : 0.f;
-                v.w = ok ? fv_virt_dz1(__uint_as_float(ra[p].w), __uint_as_float(rz[p].w), vsc.w, vsh.w, vmu.w, vis.w, vdb.w, vdg.w, lk) : 0.f;
-                *reinterpret_cast<float4*>(&As[buf][row * LDA + col]) = v;
-            } else {
-                *reinterpret_cast<u32x4*>(&As[buf][row * LDA + col]) = ra[p];
-            }
+            if constexpr (VIRT) *reinterpret_cast<float4*>(&As[buf][row * LDA + col]) = tv[p];
+            else *reinterpret_cast<u32x4*>(&As[buf][row * LDA + col]) = ra[p];
         }
         if constexpr (GATHER) {
             *reinterpret_cast<u32x4*>(&Bs[buf][(tid >> 3) * LDB + (tid & 7) * 4]) = rb[0];
@@ -218,9 +216,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
     };
 
     load();
+#pragma unroll
+    for (int p = 0; p < AL; ++p) transform(p);
     stage(0);
     __syncthreads();
     constexpr int NP = KW / 2;   // k-pairs per chunk for this wave
+    // the next chunk is staged mid-chunk; with the fused operand its rows are transformed one per k-pair pair before that
+    constexpr int IS = (VIRT && QUAD) ? 10 : NP / 2;
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int cur = (ch - ch_begin) & 1;
         const bool more = ch + 1 < ch_end;
@@ -234,7 +236,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
             readfrag(As[cur], Bs[cur], 2 * (i + 1), af1, bf1);
             __builtin_amdgcn_sched_barrier(0);
             mfma(af0, bf0);
-            if (i == NP / 2) { if (more) stage(cur ^ 1); }   // next tile lands in the other buffer mid-chunk
+            if constexpr (VIRT) {
+                if (QUAD ? (i >= 2 && i <= 8) : (i == IS)) {
+                    if constexpr (QUAD) transform((i - 2) / 2);
+                    else {
+#pragma unroll
+                        for (int p = 0; p < AL; ++p) transform(p);
+                    }
+#pragma unroll
+                    for (int q = 0; q < MB * NB; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                    }
+                    if constexpr (QUAD) pin((i - 2) / 2);
+                    else {
+#pragma unroll
+                        for (int p = 0; p < AL; ++p) pin(p);
+                    }
+                }
+            }
+            if (i == IS) { if (more) stage(cur ^ 1); }   // next tile lands in the other buffer mid-chunk
             if (i + 2 < NP) readfrag(As[cur], Bs[cur], 2 * (i + 2), af0, bf0);
             __builtin_amdgcn_sched_barrier(0);
             mfma(af1, bf1);
@@ -265,8 +286,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
 template <int TM, int TN, bool QUAD, bool GATHER>
 int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
     if (a.virt.z)
-        FV_REQUIRE(ctx, a.virt.scale && a.virt.shift && a.virt.mean && a.virt.invstd && a.virt.dbm && a.virt.dgm && a.N % 4 == 0,
-                   "wgrad: the BN-backward operand needs its six per-channel vectors and N %% 4 == 0");
+        FV_REQUIRE(ctx, a.virt.tab && a.N % 4 == 0, "wgrad: the BN-backward operand needs its per-channel table and N %% 4 == 0");
     const int ntap = GATHER ? 1 : a.taps.n;
     const int tiles = ((a.N + TM - 1) / TM) * (GATHER ? 1 : a.Cin / TN) * ntap;
     const int total_chunks = (a.M + KP - 1) / KP;

@@ -46,13 +46,36 @@ def bbox_iou_xyxy(b1, b2):
     return float(inter) / union if union != 0 else float('nan')
 
 
-def match_image(gt_boxes, det_boxes):
+def iou_matrix_device(ctx, gt_boxes, det_boxes):
+    """All (gt, detection) IoUs of one or many images in ONE kernel launch (fv_bbox_iou_pairs): gt_boxes (n,4),
+    det_boxes (m,4) as x, y, w, h -> (n, m) float64, bit-identical to bbox_iou_xyxy on the same pairs."""
+    import torch
+    from ._lib import lib, ptr
+    g = np.asarray(gt_boxes, np.float64).reshape(-1, 4); d = np.asarray(det_boxes, np.float64).reshape(-1, 4)
+    n, m = len(g), len(d)
+    if n == 0 or m == 0:
+        return np.zeros((n, m))
+    gx = np.stack([g[:, 0], g[:, 1], g[:, 0] + g[:, 2], g[:, 1] + g[:, 3]], 1)
+    dx = np.stack([d[:, 0], d[:, 1], d[:, 0] + d[:, 2], d[:, 1] + d[:, 3]], 1)
+    dev = torch.device('cuda', ctx.device)
+    a = torch.from_numpy(np.repeat(gx, m, axis=0)).to(dev); b = torch.from_numpy(np.tile(dx, (n, 1))).to(dev)
+    out = torch.empty(n * m, dtype=torch.float64, device=dev)
+    ctx.check(lib().fv_bbox_iou_pairs(ctx.handle, ptr(a), ptr(b), n * m, ptr(out)), 'fv_bbox_iou_pairs')
+    return out.cpu().numpy().reshape(n, m)
+
+
+def match_image(gt_boxes, det_boxes, ctx=None):
     """Greedy assignment of one image (evaluate.py:46-95).  gt_boxes (n,4), det_boxes (m,4) as
     x, y, w, h.  Returns the (m,) IoU assigned to each detection (-1 = unmatched), or None when no pair
-    overlaps (the reference then drops the image's detections, false positives included)."""
+    overlaps (the reference then drops the image's detections, false positives included).  ctx: an fv
+    Context -> the pair IoUs come from the device kernel (same values)."""
     out = np.full(len(det_boxes), -1.0)
     pairs = []
-    for i, g in enumerate(gt_boxes):
+    if ctx is not None:
+        with np.errstate(invalid='ignore'):
+            m = iou_matrix_device(ctx, gt_boxes, det_boxes)
+            pairs = [(int(i), int(j), float(m[i, j])) for i, j in zip(*np.nonzero(m > 0.))]
+    for i, g in enumerate(gt_boxes if ctx is None else []):
         gb = (g[0], g[1], g[0] + g[2], g[1] + g[3])
         for j, d in enumerate(det_boxes):
             iou = bbox_iou_xyxy(gb, (d[0], d[1], d[0] + d[2], d[1] + d[3]))
@@ -70,7 +93,7 @@ def match_image(gt_boxes, det_boxes):
     return out
 
 
-def detection_ious(gt_df, sol_df):
+def detection_ious(gt_df, sol_df, ctx=None):
     """-> (confidences, assigned IoUs) of every detection on a ground-truth image that has detections,
     in ground-truth image order (evaluate.py:39-101)."""
     sol_groups = {k: v for k, v in sol_df.groupby(0, sort=True)}
@@ -79,7 +102,7 @@ def detection_ious(gt_df, sol_df):
         rel = sol_groups.get(image_id)
         if rel is None or len(rel) == 0:
             continue
-        iou = match_image(df.iloc[:, 3:7].to_numpy(dtype=np.float64), rel.iloc[:, 1:5].to_numpy(dtype=np.float64))
+        iou = match_image(df.iloc[:, 3:7].to_numpy(dtype=np.float64), rel.iloc[:, 1:5].to_numpy(dtype=np.float64), ctx)
         if iou is None:
             continue
         conf.append(rel.iloc[:, 5].to_numpy(dtype=np.float64))
@@ -107,12 +130,13 @@ def integrate_pr(ps, rs):
     return quad(lambda x: func(x), rs[0], rs[-1])[0]
 
 
-def cal_mAP_fd(gt_path, sol_path, iou_th):
-    """-> (ps, rs, mAP) exactly as the reference's signature (evaluate.py:27, 127)."""
+def cal_mAP_fd(gt_path, sol_path, iou_th, ctx=None):
+    """-> (ps, rs, mAP) exactly as the reference's signature (evaluate.py:27, 127); ctx: optional fv Context
+    (pair IoUs on the device)."""
     import pandas as pd
     sol_df = pd.read_csv(sol_path, header=None)
     gt_df = pd.read_csv(gt_path)
-    conf, ious = detection_ious(gt_df, sol_df)
+    conf, ious = detection_ious(gt_df, sol_df, ctx)
     ps, rs = pr_curve(conf, ious, gt_df.shape[0], iou_th)
     return ps, rs, integrate_pr(ps, rs)
 

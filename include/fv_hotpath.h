@@ -57,6 +57,11 @@ int fv_set_conv_dma(fv_ctx* ctx, int on);
  * fix-up kernel sums in fixed slice order before the epilogue.  Deterministic; changes only the
  * fp32 summation order of those tiles (default: on). */
 int fv_set_tail_split(fv_ctx* ctx, int on);
+/* fv_train_step's BatchNorm backward.  0 (default): one pass per layer writes dz (the d-beta / d-gamma sums come
+ * from the epilogue of the data-gradient above it).  1: no pass at all -- the weight- and data-gradient kernels of
+ * the layer form dz from (g, z) while staging their operand (fv_conv2d_dgrad_fused / fv_conv2d_wgrad_fused).
+ * Bit-identical gradients; measured slower on MI355X (63.7 vs 58.7 ms per step), kept as a switch. */
+int fv_set_fused_bn_backward(fv_ctx* ctx, int on);
 /* The per-operator conv entry points (fv_conv2d_forward / fv_conv2d_dgrad) have no workspace
  * argument; a caller that wants the tail split there lends device scratch here (NULL, 0 = none;
  * 64 MiB covers every Darknet-53 shape at batch 40).  The buffer must stay valid until the calls that
@@ -90,6 +95,11 @@ int fv_decode_nms(fv_ctx* ctx, const float* head, int nimg, int grid, int image_
                   double conf_th, double iou_th, int num_cands, int32_t* boxes, int32_t* cell,
                   float* obj, float* score, int32_t* count);
 
+
+/* Batched bbox_iou (yd.py:183-194) for the accuracy metric cal_mAP_fd (evaluate.py:46-75):
+ * boxes_a, boxes_b [npairs][4] float64 xmin,ymin,xmax,ymax (device) -> iou [npairs] float64, bit-identical to
+ * the reference's Python-float arithmetic (nan / inf for a zero union, as NumPy division gives). */
+int fv_bbox_iou_pairs(fv_ctx* ctx, const double* boxes_a, const double* boxes_b, int64_t npairs, double* iou);
 
 /* ------------------------------------------------------------------ network description
  * The FaceDetector network: the first 52 conv+BN+LeakyReLU(0.1) layers / 23 residual adds of
@@ -223,6 +233,27 @@ int fv_conv2d_dgrad_bnred(fv_ctx* ctx, const float* dy, const float* w_t, int B,
 int fv_bn_bwd_slots(fv_ctx* ctx, const float* g, const float* z, const float* scale, const float* shift,
                     const float* mean, const float* invstd, int64_t rows, int C, float leaky, double* slots,
                     int nslot, int reduced, float* dbeta, float* dgamma, float* dz);
+/* ---- BatchNorm's backward without a pass of its own (what fv_train_step runs): the consumers of
+ * dz = dL/d(pre-BN output) take g = dL/d(activated output) and z instead and form, while staging their
+ * operand between matrix instructions,
+ *     dz = scale*((g*leaky'(z*scale+shift) - dbm) - ((z-mean)*invstd)*dgm)
+ * -- bit for bit what fv_bn_bwd_slots writes.  fv_bn_bwd_coeff turns the slot sums into d-beta, d-gamma
+ * and the per-channel table `tab` [C/4][6][4] floats: for each group of four channels the float4s
+ * scale, shift, mean, invstd, dbm = d-beta/rows, dgm = d-gamma/rows. */
+int fv_bn_bwd_coeff(fv_ctx* ctx, const double* slots, int nslot, int64_t rows, int C, const float* scale,
+                    const float* shift, const float* mean, const float* invstd, float* dbeta, float* dgamma,
+                    float* tab);
+/* fv_conv2d_dgrad with dy given as (g, z, tab of the layer the conv belongs to: cout_pad channels).
+ * bn_z != NULL additionally runs the fused d-beta/d-gamma reduction of the layer below, exactly as
+ * fv_conv2d_dgrad_bnred (its vectors are [cin]). */
+int fv_conv2d_dgrad_fused(fv_ctx* ctx, const float* g, const float* z, const float* tab, float leaky,
+                          const float* w_t, int B, int H, int W, int cin, int cout_pad, int ksize, int stride,
+                          const float* addend, float* dx, const float* bn_z, const float* bn_scale,
+                          const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_slots,
+                          int bn_nslot);
+/* fv_conv2d_wgrad with dy given the same way (cout % 4 == 0, dy_stride == cout). */
+int fv_conv2d_wgrad_fused(fv_ctx* ctx, const float* x, const float* g, const float* z, const float* tab,
+                          float leaky, int B, int H, int W, int cin, int cout, int ksize, int stride, float* dw);
 /* loss = mean((yp-yt)^2) over [rows][C]; dy [rows][c_pad] = 2(yp-yt)/(rows*C) zero padded;
  * dbias[C] = column sums of dy (may be NULL). */
 int fv_mse_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int c_pad,

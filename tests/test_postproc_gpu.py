@@ -147,3 +147,35 @@ def test_letterbox_batch_equals_single_launches(ctx):
     packed = pack_images(raws[:3])
     out2, _ = letterbox_batch_device(ctx, None, 416, torch.device('cuda', 0), packed=packed)
     assert torch.equal(out2, out[:3])
+
+
+def test_bbox_iou_pairs_kernel_bit_exact(ctx, golden_dir, tmp_path):
+    """fv_bbox_iou_pairs (the batched IoU under cal_mAP_fd): bit-identical to the reference's
+    bbox_iou golden (4000 integer-corner pairs incl. nan / inf for zero unions) and, on float csv-style boxes, to
+    the host restatement; cal_mAP_fd gives the same curve with the device IoUs."""
+    import torch
+    from face_vijnana_yolov3_amd import evaluate as ev
+    from face_vijnana_yolov3_amd._lib import lib, ptr
+    g = np.load(os.path.join(golden_dir, 'iou_cases.npz'))
+    a = torch.from_numpy(g['a'].astype(np.float64)).cuda(); b = torch.from_numpy(g['b'].astype(np.float64)).cuda()
+    out = torch.empty(len(g['iou']), dtype=torch.float64, device='cuda')
+    ctx.check(lib().fv_bbox_iou_pairs(ctx.handle, ptr(a), ptr(b), out.numel(), ptr(out)), 'fv_bbox_iou_pairs')
+    assert np.array_equal(out.cpu().numpy(), g['iou'], equal_nan=True)
+    rng = np.random.default_rng(4)
+    gt = np.concatenate([rng.uniform(0, 400, (37, 2)), rng.uniform(5, 120, (37, 2))], 1)
+    det = np.concatenate([rng.uniform(0, 400, (53, 2)), rng.uniform(5, 120, (53, 2))], 1)
+    det[:10] = gt[:10] + rng.normal(0, 3, (10, 4))
+    m = ev.iou_matrix_device(ctx, gt, det)
+    want = np.array([[ev.bbox_iou_xyxy((p[0], p[1], p[0] + p[2], p[1] + p[3]), (q[0], q[1], q[0] + q[2], q[1] + q[3])) for q in det] for p in gt])
+    assert np.array_equal(m, want, equal_nan=True)
+    assert np.array_equal(ev.match_image(gt, det), ev.match_image(gt, det, ctx))
+    gtp = os.path.join(tmp_path, 'validation.csv'); sol = os.path.join(tmp_path, 'solution.csv')
+    with open(gtp, 'w') as f:
+        f.write('FACE_ID,FILE,SUBJECT_ID,FACE_X,FACE_Y,FACE_WIDTH,FACE_HEIGHT\n')
+        for k, r in enumerate(gt):
+            f.write('%d,img_%d.jpg,1,%r,%r,%r,%r\n' % (k, k % 5, r[0], r[1], r[2], r[3]))
+    with open(sol, 'w') as f:
+        for k, r in enumerate(det):
+            f.write('img_%d.jpg,%r,%r,%r,%r,%r\n' % (k % 5, r[0], r[1], r[2], r[3], float(rng.uniform(0.5, 1))))
+    p1, r1, m1 = ev.cal_mAP_fd(gtp, sol, 0.5); p2, r2, m2 = ev.cal_mAP_fd(gtp, sol, 0.5, ctx)
+    assert np.array_equal(p1, p2) and np.array_equal(r1, r2) and m1 == m2
