@@ -41,3 +41,10 @@ int fv_ew_bn_fold_all(fv_ctx* ctx, const float* params, const float* state, int 
                       float* scale, float* shift);
 int fv_ew_fd_loss(fv_ctx* ctx, const float* yp, const float* yt, int cells, int Cpad, float* loss, float* dy);
 int fv_ew_upsample_concat(fv_ctx* ctx, const float* src, const float* skip, float* out, int B, int Hs, int Ws, int C1, int C2);
+// three-scale training (net_yolov3.hip): backward of upsample+concat, bias-gradient column sums, the per-scale detection loss
+int fv_ew_upsample_concat_bwd(fv_ctx* ctx, const float* g, float* g_up, float* g_skip, int B, int Hs, int Ws, int C1, int C2);
+int fv_ew_colsum_chunks(long long rows);
+int fv_ew_colsum(fv_ctx* ctx, const float* dy, long long rows, int C, int Cpad, double* part /*[chunks][C]*/, float* out);
+int fv_ew_yolo_loss_blocks(long long nbox);
+int fv_ew_yolo_loss_part(fv_ctx* ctx, const float* t, const float* y, long long cells, int ncls, int A, int Cpad, float* dy, double* part);
+int fv_ew_yolo_loss_finish(fv_ctx* ctx, const double* part, const long long* cells3, int A, float* loss);

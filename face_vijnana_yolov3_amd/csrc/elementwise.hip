@@ -806,3 +806,144 @@ int fv_ew_upsample_concat(fv_ctx* ctx, const float* src, const float* skip, floa
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }
+
+
+// ---------------------------------------------------------------- three-scale training
+// Backward of UpSampling2D(2) + concatenate (yd.py:282-283, 298-299): g [B][2Hs][2Ws][C1+C2] ->
+//   g_up [B][Hs][Ws][C1] = sum of the 2x2 block of the first C1 channels,  g_skip [B][2Hs][2Ws][C2] = the other C2.
+namespace {
+__global__ __launch_bounds__(256) void upsample_concat_bwd_kernel(const float4* __restrict__ g, float4* __restrict__ g_up,
+                                                                  float4* __restrict__ g_skip, int B, int Hs, int Ws, int C1, int C2) {
+    const int c4 = (C1 + C2) >> 2, c14 = C1 >> 2, c24 = C2 >> 2;
+    const long long n_up = (long long)B * Hs * Ws * c14, n_sk = (long long)B * 4 * Hs * Ws * c24;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_up + n_sk; i += (long long)gridDim.x * blockDim.x) {
+        if (i < n_up) {
+            const int c = (int)(i % c14);
+            const long long pix = i / c14;
+            const int w = (int)(pix % Ws), h = (int)((pix / Ws) % Hs), b = (int)(pix / ((long long)Hs * Ws));
+            const long long r0 = (((long long)b * 2 * Hs + 2 * h) * 2 * Ws + 2 * w) * c4 + c, r1 = r0 + (long long)2 * Ws * c4;
+            const float4 p = g[r0], q = g[r0 + c4], r = g[r1], t = g[r1 + c4];   // fixed order: deterministic
+            float4 o;
+            o.x = (p.x + q.x) + (r.x + t.x); o.y = (p.y + q.y) + (r.y + t.y); o.z = (p.z + q.z) + (r.z + t.z); o.w = (p.w + q.w) + (r.w + t.w);
+            g_up[i] = o;
+        } else {
+            const long long j = i - n_up;
+            const int c = (int)(j % c24);
+            const long long pix = j / c24;
+            g_skip[j] = g[pix * c4 + c14 + c];
+        }
+    }
+}
+
+// column sums of dy [rows][Cpad] over the first C columns -> out[C] (bias gradient of a detection conv); two stages, fixed order
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ dy, long long rows, int C, int Cpad, double* __restrict__ part) {
+    __shared__ double s[8][33];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+    double acc = 0.0;
+    if (c < C)
+        for (long long r = blockIdx.y * 8 + rl; r < rows; r += 8 * gridDim.y) acc += (double)dy[r * Cpad + c];
+    s[rl][threadIdx.x & 31] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += s[k][threadIdx.x];
+        part[(size_t)blockIdx.y * C + c] = t;
+    }
+}
+__global__ void colsum_finish_kernel(const double* __restrict__ part, int nchunk, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double t = 0.0;
+    for (int k = 0; k < nchunk; ++k) t += part[(size_t)k * C + c];
+    out[c] = (float)t;
+}
+
+// Detection loss of one scale -- the reference defines none for its three-scale graph (yd.py:217-311 is inference only); this
+// generalises its fd_loss (fd.py:59-64: (BCE(objectness) + mean |box error| + BCE(class)) / 3 per cell) to 3 anchors per cell
+// and `ncls` classes, with the cross-entropies taken on LOGITS (the head is linear; fd_loss as written feeds a linear output
+// to a probability-space BCE):  per (cell, anchor)  ( bce(t4, y4) + mean_{k<4} |t_k - y_k| + mean_c bce(t_{5+c}, y_{5+c}) ) / 3,
+// bce(t, y) = max(t, 0) - t*y + log1p(exp(-|t|));  scale loss = mean over cells x anchors.  dy = its gradient, zero padded.
+__device__ __forceinline__ double bce_logit(double t, double y) { return fmax(t, 0.0) - t * y + log1p(exp(-fabs(t))); }
+__global__ __launch_bounds__(256) void yolo_loss_part_kernel(const float* __restrict__ t, const float* __restrict__ y, long long nbox,
+                                                             int ncls, int A, int Cpad, float* __restrict__ dy, double* __restrict__ part) {
+    // one wave per (cell, anchor) box: lanes stride over the 5 + ncls entries, wave-reduce the box loss
+    __shared__ double s_w[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int E = 5 + ncls;
+    const double gs = 1.0 / (3.0 * (double)nbox);
+    double acc = 0.0;
+    for (long long bx = (long long)blockIdx.x * 4 + wave; bx < nbox; bx += (long long)gridDim.x * 4) {
+        const long long cell = bx / A;
+        const int an = (int)(bx - cell * A);
+        const float* tp = t + cell * (long long)(A * E) + (long long)an * E;
+        const float* yp = y + cell * (long long)(A * E) + (long long)an * E;
+        float* gp = dy + cell * Cpad + (long long)an * E;
+        double l = 0.0;
+        for (int e = lane; e < E; e += 64) {
+            const double tv = (double)tp[e], yv = (double)yp[e];
+            double g;
+            if (e < 4) { const double d = tv - yv; l += 0.25 * fabs(d); g = 0.25 * (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0)); }
+            else {
+                const double w = e == 4 ? 1.0 : 1.0 / (double)ncls;
+                l += w * bce_logit(tv, yv);
+                g = w * (1.0 / (1.0 + exp(-tv)) - yv);
+            }
+            gp[e] = (float)(g * gs);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+        acc += l / 3.0;
+        if (an == A - 1) for (int e = A * E + lane; e < Cpad; e += 64) dy[cell * Cpad + e] = 0.f;   // padding columns
+    }
+    if (lane == 0) s_w[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+__global__ void yolo_loss_finish_kernel(const double* __restrict__ part, int n0, int n1, int n2, double inv0, double inv1, double inv2,
+                                        float* __restrict__ loss) {
+    if (threadIdx.x || blockIdx.x) return;
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = 0; i < n0; ++i) a += part[i];
+    for (int i = 0; i < n1; ++i) b += part[n0 + i];
+    for (int i = 0; i < n2; ++i) c += part[n0 + n1 + i];
+    *loss = (float)(a * inv0 + b * inv1 + c * inv2);
+}
+}  // namespace
+
+int fv_ew_upsample_concat_bwd(fv_ctx* ctx, const float* g, float* g_up, float* g_skip, int B, int Hs, int Ws, int C1, int C2) {
+    FV_REQUIRE(ctx, C1 % 4 == 0 && C2 % 4 == 0, "upsample_concat_bwd: channels must be multiples of 4");
+    const long long n4 = (long long)B * Hs * Ws * (C1 / 4) + (long long)B * 4 * Hs * Ws * (C2 / 4);
+    FvProfScope ps(ctx, "upsample_concat_bwd_kernel", 0.0, 4.0 * B * Hs * Ws * (5.0 * C1 + 8.0 * C2));
+    long long gr = (n4 + 255) / 256;
+    hipLaunchKernelGGL(upsample_concat_bwd_kernel, dim3((unsigned)(gr > 4096 ? 4096 : (gr < 1 ? 1 : gr))), dim3(256), 0, ctx->stream,
+                       (const float4*)g, (float4*)g_up, (float4*)g_skip, B, Hs, Ws, C1, C2);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_ew_colsum_chunks(long long rows) { long long n = (rows + 511) / 512; return (int)(n < 1 ? 1 : (n > 64 ? 64 : n)); }
+int fv_ew_colsum(fv_ctx* ctx, const float* dy, long long rows, int C, int Cpad, double* part, float* out) {
+    const int nchunk = fv_ew_colsum_chunks(rows);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((C + 31) / 32, nchunk), dim3(256), 0, ctx->stream, dy, rows, C, Cpad, part);
+    FV_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, part, nchunk, C, out);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_ew_yolo_loss_blocks(long long nbox) { long long n = (nbox + 3) / 4; return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n)); }
+int fv_ew_yolo_loss_part(fv_ctx* ctx, const float* t, const float* y, long long cells, int ncls, int A, int Cpad, float* dy, double* part) {
+    FV_REQUIRE(ctx, Cpad >= A * (5 + ncls), "yolo_loss: Cpad too small");
+    const long long nbox = cells * A;
+    hipLaunchKernelGGL(yolo_loss_part_kernel, dim3(fv_ew_yolo_loss_blocks(nbox)), dim3(256), 0, ctx->stream, t, y, nbox, ncls, A, Cpad, dy, part);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+int fv_ew_yolo_loss_finish(fv_ctx* ctx, const double* part, const long long* cells3, int A, float* loss) {
+    const int n0 = fv_ew_yolo_loss_blocks(cells3[0] * A), n1 = fv_ew_yolo_loss_blocks(cells3[1] * A), n2 = fv_ew_yolo_loss_blocks(cells3[2] * A);
+    hipLaunchKernelGGL(yolo_loss_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, part, n0, n1, n2, 1.0 / ((double)cells3[0] * A),
+                       1.0 / ((double)cells3[1] * A), 1.0 / ((double)cells3[2] * A), loss);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}

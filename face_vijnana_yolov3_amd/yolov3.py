@@ -34,6 +34,10 @@ class Yolov3(object):
         self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.dev)
         self.state = torch.zeros(self.n_state, dtype=torch.float32, device=self.dev)
         self._ws = {}
+        self._tws = {}
+        self.grads = self.m = self.v = None
+        self.iterations = 0
+        self._loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
 
     def set_params(self, params, state):
         self.params.copy_(torch.as_tensor(params, dtype=torch.float32).reshape(-1))
@@ -71,6 +75,59 @@ class Yolov3(object):
                                      ws.numel(), ptr(ys[0]), ptr(ys[1]), ptr(ys[2]))
         self.ctx.check(rc, 'fv_yolov3_forward')
         return ys
+
+
+    # ------------------------------------------------------------------ training (fv_yolov3_train_step)
+    def _train_ws(self, B, S):
+        key = (B, S)
+        if key not in self._tws:
+            n = int(lib().fv_yolov3_train_workspace_bytes(B, S, self.out_channels))
+            self._tws = {key: torch.empty(n, dtype=torch.uint8, device=self.dev)}
+        return self._tws[key]
+
+    def forward_backward(self, x, targets):
+        """x (B,S,S,3); targets: three tensors shaped like the outputs, (B,g,g,3*(5+classes)).  Gradients land in
+        self.grads; returns the loss (1-element CUDA tensor)."""
+        if self.grads is None:
+            self.grads = torch.zeros_like(self.params); self.m = torch.zeros_like(self.params); self.v = torch.zeros_like(self.params)
+        x = torch.as_tensor(x).to(device=self.dev, dtype=torch.float32).contiguous()
+        B, S = x.shape[0], x.shape[1]
+        t = [torch.as_tensor(y).to(device=self.dev, dtype=torch.float32).contiguous() for y in targets]
+        for y, dv in zip(t, (32, 16, 8)):
+            assert y.numel() == B * (S // dv) ** 2 * self.out_channels, tuple(y.shape)
+        ws = self._train_ws(B, S)
+        rc = lib().fv_yolov3_train_step(self.ctx.handle, ptr(self.params), ptr(self.state), ptr(x), ptr(t[0]), ptr(t[1]), ptr(t[2]), B, S,
+                                        self.out_channels, ptr(ws), ws.numel(), ptr(self.grads), ptr(self._loss))
+        self.ctx.check(rc, 'fv_yolov3_train_step')
+        return self._loss
+
+    def adam_step(self, lr, beta_1, beta_2, decay=0.0, eps=1e-7):
+        rc = lib().fv_adam_step(self.ctx.handle, ptr(self.params), ptr(self.grads), ptr(self.m), ptr(self.v), self.n_params,
+                                self.iterations, float(lr), float(beta_1), float(beta_2), float(eps), float(decay))
+        self.ctx.check(rc, 'fv_adam_step')
+        self.iterations += 1
+
+    def train_on_batch(self, x, targets, lr, beta_1, beta_2, decay=0.0):
+        loss = self.forward_backward(x, targets)
+        self.adam_step(lr, beta_1, beta_2, decay)
+        return loss
+
+    def leaky_slopes_taken(self, B, S):
+        """Per BN layer (fv_yolov3_layer order, detection convs skipped): bool tensor, True where the last train step
+        took the positive LeakyReLU branch (see Engine.leaky_slopes_taken)."""
+        ws = self._train_ws(B, S)
+        out = []
+        for l, d in enumerate(self.layers):
+            if not d['has_bn']:
+                continue
+            t = []
+            for code in (0, 4, 5):
+                off, cnt = ctypes.c_size_t(0), ctypes.c_int64(0)
+                assert lib().fv_yolov3_train_workspace_tensor(B, S, self.out_channels, l, code, ctypes.byref(off), ctypes.byref(cnt)) == 0
+                t.append(ws[off.value:off.value + 4 * cnt.value].view(torch.float32))
+            g = S // d['out_div']
+            out.append((t[0].view(B, g, g, d['cout']) * t[1] + t[2]) > 0)
+        return out
 
 
 def decode_nms(ctx, y13, y26, y52, image_hw, net_hw=(416, 416), anchors=COCO_ANCHORS, obj_thresh=0.5, nms_thresh=0.45):

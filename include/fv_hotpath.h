@@ -286,6 +286,23 @@ size_t fv_yolov3_workspace_bytes(int batch, int image_size, int out_channels);
 int fv_yolov3_forward(fv_ctx* ctx, const float* params, const float* bn_state, const float* x, int batch,
                       int image_size, int out_channels, void* workspace, size_t workspace_bytes,
                       float* y13, float* y26, float* y52);
+/* TRAINING the three-scale graph (SURVEY 8f row 4 -- "three-scale YOLO head + bbox/objectness loss" of the
+ * north star; the reference builds this graph for inference only and defines no loss for it, so this is the
+ * build's own definition, restated in oracle/net_oracle.py).  One step's forward (training-mode BN in all 72
+ * BN layers, moving statistics updated) + loss + backward through the heads, both UpSampling2D+concatenate
+ * routes and the base; gradients of every parameter of the fv_yolov3_layer layout into `grads` (overwritten).
+ * yt13 / yt26 / yt52: targets shaped like the outputs, [batch][g][g][3][5+classes].  Loss = sum over the
+ * three scales of the mean over (cell, anchor) of
+ *     ( bce(t4, y4) + mean_{k<4} |t_k - y_k| + mean_c bce(t_{5+c}, y_{5+c}) ) / 3
+ * -- the reference's fd_loss (fd.py:59-64) generalised to 3 anchors and `classes` classes, with the
+ * cross-entropies on logits: bce(t, y) = max(t,0) - t*y + log1p(exp(-|t|)).  Follow with fv_adam_step. */
+size_t fv_yolov3_train_workspace_bytes(int batch, int image_size, int out_channels);
+int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float* x, const float* yt13,
+                         const float* yt26, const float* yt52, int batch, int image_size, int out_channels,
+                         void* workspace, size_t workspace_bytes, float* grads, float* loss);
+/* as fv_train_workspace_tensor, for the workspace of fv_yolov3_train_step (BN layers of fv_yolov3_layer) */
+int fv_yolov3_train_workspace_tensor(int batch, int image_size, int out_channels, int layer, int which,
+                                     size_t* offset_bytes, int64_t* count);
 /* replaces decode_netout x3 (yd.py:335-387, with its anchor skip list), correct_yolo_boxes
  * (yd.py:389-404) and do_nms (yd.py:426-444) for ONE image: outputs in the reference's list order;
  * boxes [capacity][4] int32 xmin,ymin,xmax,ymax in image pixels, objness [capacity],

@@ -270,15 +270,19 @@ def yolov3_init(seed=11, nclass_ch=255, dtype=torch.float32):
     return p.to(dtype), st.to(dtype)
 
 
-def yolov3_forward(params, state, x_nhwc, nclass_ch=255):
-    """Inference forward of make_yolov3_model (yolov3_detect.py:217-311): -> [yolo_82, yolo_94,
-    yolo_106] as NHWC tensors (B,S/32,S/32,C), (B,S/16,..), (B,S/8,..)."""
+def yolov3_forward(params, state, x_nhwc, nclass_ch=255, training=False, positive=None, new_state=None):
+    """Forward of make_yolov3_model (yolov3_detect.py:217-311): -> [yolo_82, yolo_94, yolo_106] as NHWC
+    tensors (B,S/32,S/32,C), (B,S/16,..), (B,S/8,..).  training=False: the reference's inference graph
+    (moving statistics).  training=True (the build's extension): batch statistics in every
+    BN layer, Keras-style moving-statistics update written into `new_state` if given; positive: forced
+    LeakyReLU branches, one bool NHWC tensor per BN layer in layout order (see forward())."""
     ents, _, _ = yolov3_layout(nclass_ch)
     x = x_nhwc.permute(0, 3, 1, 2)
     skip = None
     t = {}
     outs = []
     nbase = 52
+    bn_i = [0]
 
     def block(e, x):
         k, cin, cout = e['k'], e['cin'], e['cout']
@@ -286,10 +290,23 @@ def yolov3_forward(params, state, x_nhwc, nclass_ch=255):
         z = _conv(x, w, k, e['s'])
         if not e['has_bn']:
             return z + params[e['bias_off']:e['bias_off'] + cout].view(1, -1, 1, 1)
-        mean = state[e['mean_off']:e['mean_off'] + cout]; var = state[e['var_off']:e['var_off'] + cout]
+        if training:
+            mean = z.mean(dim=(0, 2, 3)); var = ((z - mean.view(1, -1, 1, 1)) ** 2).mean(dim=(0, 2, 3))
+            if new_state is not None:
+                n = z.numel() // cout
+                with torch.no_grad():
+                    new_state[e['mean_off']:e['mean_off'] + cout] = BN_MOMENTUM * state[e['mean_off']:e['mean_off'] + cout] + (1 - BN_MOMENTUM) * mean
+                    new_state[e['var_off']:e['var_off'] + cout] = BN_MOMENTUM * state[e['var_off']:e['var_off'] + cout] \
+                        + (1 - BN_MOMENTUM) * var * (n / (n - (1.0 + BN_EPS)))
+        else:
+            mean = state[e['mean_off']:e['mean_off'] + cout]; var = state[e['var_off']:e['var_off'] + cout]
         y = (z - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + BN_EPS) * params[e['gamma_off']:e['gamma_off'] + cout].view(1, -1, 1, 1) \
             + params[e['beta_off']:e['beta_off'] + cout].view(1, -1, 1, 1)
-        return F.leaky_relu(y, LEAKY)
+        i = bn_i[0]; bn_i[0] += 1
+        if positive is None:
+            return F.leaky_relu(y, LEAKY)
+        pos = positive[i].permute(0, 3, 1, 2)
+        return y * torch.where(pos, torch.ones((), dtype=y.dtype), torch.full((), LEAKY, dtype=y.dtype))
 
     for li, e in enumerate(ents[:nbase]):
         if e['role'] == 'res_a':
@@ -323,3 +340,27 @@ def yolov3_forward(params, state, x_nhwc, nclass_ch=255):
         if not e['has_bn']:
             outs.append(prev.permute(0, 2, 3, 1).contiguous())
     return outs
+
+
+def yolo_scale_loss(t, y, nclass):
+    """The build's three-scale detection loss for ONE scale (the reference defines none; include/fv_hotpath.h
+    fv_yolov3_train_step): t, y (B,g,g,3*(5+nclass)); per (cell, anchor)
+    (bce(t4,y4) + mean_{k<4}|t_k-y_k| + mean_c bce(t_{5+c},y_{5+c})) / 3 with bce on logits; mean over cells x anchors."""
+    B, g = t.shape[0], t.shape[1]
+    t = t.reshape(B, g, g, 3, 5 + nclass); y = y.reshape(B, g, g, 3, 5 + nclass)
+    bce = lambda a, b: torch.clamp(a, min=0) - a * b + torch.log1p(torch.exp(-a.abs()))
+    obj = bce(t[..., 4], y[..., 4])
+    box = (t[..., :4] - y[..., :4]).abs().mean(-1)
+    cls = bce(t[..., 5:], y[..., 5:]).mean(-1)
+    return ((obj + box + cls) / 3.0).mean()
+
+
+def yolov3_train_step_grads(params, state, x, targets, nclass_ch=255, positive=None):
+    """One fwd (training BN) + three-scale loss + bwd: -> (loss, flat grads, new_state)."""
+    p = params.clone().requires_grad_(True)
+    new_state = state.clone()
+    outs = yolov3_forward(p, state, x, nclass_ch, training=True, positive=positive, new_state=new_state)
+    nclass = nclass_ch // 3 - 5
+    loss = sum(yolo_scale_loss(o, y, nclass) for o, y in zip(outs, targets))
+    (g,) = torch.autograd.grad(loss, p)
+    return loss.detach(), g, new_state

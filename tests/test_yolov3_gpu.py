@@ -159,3 +159,65 @@ def test_decode_nms_properties_at_full_size(model):
         ii, jj = np.triu_indices(len(idx), 1)
         iou = opp.bbox_iou(b[idx][ii], b[idx][jj])
         assert not np.any(iou >= 0.5)
+
+
+# ------------------------------------------------------------------------------------------ training
+def _train_setup(out_ch, B, S, seed):
+    from oracle import net_oracle as no
+    p64, s64 = no.yolov3_init(seed, out_ch, torch.float64)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.rand((B, S, S, 3), dtype=torch.float64, generator=g)
+    tg = []
+    for d in (32, 16, 8):
+        t = torch.rand((B, S // d, S // d, out_ch), dtype=torch.float64, generator=g)
+        t4 = t.view(B, S // d, S // d, 3, out_ch // 3)
+        t4[..., 4] = (t4[..., 4] > 0.8).double(); t4[..., 5:] = (t4[..., 5:] > 0.7).double()     # objectness / class targets in {0, 1}
+        tg.append(t)
+    return p64, s64, x, tg
+
+
+@pytest.mark.parametrize('out_ch,B,S', [(27, 2, 64), (27, 3, 96), (255, 1, 64)])
+def test_three_scale_train_step_matches_oracle(out_ch, B, S):
+    """fv_yolov3_train_step: forward with training-mode BN in all 72 BN layers, the three-scale loss, backward through
+    the heads, both upsample+concat routes and the base -- against the float64 oracle evaluated on the device's side of
+    every LeakyReLU kink (tests/test_net_gpu.py explains the method): loss, BN moving state and EVERY gradient tensor
+    (relative L2 <= max(6 x the float32 oracle's own error, 4e-5))."""
+    from face_vijnana_yolov3_amd.yolov3 import Yolov3
+    from oracle import net_oracle as no
+    model = Yolov3(0, out_channels=out_ch)
+    p64, s64, x, tg = _train_setup(out_ch, B, S, 21)
+    model.set_params(p64.float(), s64.float())
+    loss = model.forward_backward(x.float(), [t.float() for t in tg])
+    torch.cuda.synchronize()
+    pos = [m.cpu() for m in model.leaky_slopes_taken(B, S)]
+    l64, g64, ns64 = no.yolov3_train_step_grads(p64, s64, x, tg, out_ch, positive=pos)
+    l32, g32, ns32 = no.yolov3_train_step_grads(p64.float(), s64.float(), x.float(), [t.float() for t in tg], out_ch, positive=pos)
+    assert abs(loss.item() - l64.item()) <= 4 * abs(l32.item() - l64.item()) + 2e-6 * abs(l64.item())
+    e_gpu = (model.state.cpu().double() - ns64).abs().max().item(); e_cpu = (ns32.double() - ns64).abs().max().item()
+    assert e_gpu <= 4 * e_cpu + 1e-6 * max(1.0, ns64.abs().max().item())
+    ents, n, _ = no.yolov3_layout(out_ch)
+    g = model.grads.cpu().double()
+    worst = 0.0
+    for e in ents:
+        k, cin, cout = e['k'], e['cin'], e['cout']
+        parts = [('dW', slice(e['w_off'], e['w_off'] + cout * k * k * cin))]
+        parts += [('dgamma', slice(e['gamma_off'], e['gamma_off'] + cout)), ('dbeta', slice(e['beta_off'], e['beta_off'] + cout))] if e['has_bn'] \
+            else [('dbias', slice(e['bias_off'], e['bias_off'] + cout))]
+        for nm, sl in parts:
+            n64 = g64[sl].norm().item()
+            rel = (g[sl] - g64[sl]).norm().item() / max(n64, 1e-30)
+            rel32 = (g32[sl].double() - g64[sl]).norm().item() / max(n64, 1e-30)
+            assert rel <= max(6 * rel32, 4e-5), '%s %s: rel L2 err %.3e (cpu fp32 %.3e)' % (nm, e['name'], rel, rel32)
+            worst = max(worst, rel)
+    print('three-scale step out_ch=%d B=%d S=%d: worst rel-L2 %.2e' % (out_ch, B, S, worst))
+
+
+def test_three_scale_training_reduces_the_loss():
+    from face_vijnana_yolov3_amd.yolov3 import Yolov3
+    model = Yolov3(0, out_channels=27)
+    p64, s64, x, tg = _train_setup(27, 4, 96, 5)
+    model.set_params(p64.float(), s64.float())
+    xs, ts = x.float().cuda(), [t.float().cuda() for t in tg]
+    losses = [model.train_on_batch(xs, ts, 1e-4, 0.9, 0.999).item() for _ in range(40)]
+    assert all(np.isfinite(losses)) and bool(torch.isfinite(model.params).all())
+    assert losses[-1] < 0.8 * losses[0], (losses[0], losses[-1])
