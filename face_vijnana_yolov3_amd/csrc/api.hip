@@ -66,6 +66,12 @@ int fv_set_tail_split(fv_ctx* ctx, int on) {
     return FV_OK;
 }
 
+int fv_set_conv0_direct(fv_ctx* ctx, int on) {
+    if (!ctx) return FV_ERR_INVALID;
+    ctx->conv0_direct = on != 0;
+    return FV_OK;
+}
+
 int fv_set_fused_bn_backward(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;
     ctx->fused_bn_bwd = on != 0;

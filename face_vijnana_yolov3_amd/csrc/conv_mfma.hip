@@ -887,6 +887,7 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
                             a.Hl == a.Hin && a.Wl == a.Win,
                    "conv: Cin=%d is only supported as a 3x3 stride-1 pad-1 layer with 9*Cin<=32 "
                    "(weights packed [n][32])", a.Cin);
+        if (ctx->conv0_direct && fv_conv0_direct_ok(a)) return fv_conv0_direct_launch(ctx, a);
         if (a.Nout > 64) return launch_cfg<128, 2, 2, true>(ctx, a);
         if (a.Nout > 32) return launch_cfg<64, 2, 2, true>(ctx, a);
         return launch_cfg<32, 4, 1, true>(ctx, a);

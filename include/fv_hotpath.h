@@ -57,6 +57,9 @@ int fv_set_conv_dma(fv_ctx* ctx, int on);
  * fix-up kernel sums in fixed slice order before the epilogue.  Deterministic; changes only the
  * fp32 summation order of those tiles (default: on). */
 int fv_set_tail_split(fv_ctx* ctx, int on);
+/* First layer (3 -> 32 channels, K = 27, HBM-bound): 1 (default) a direct vector-FMA kernel with an LDS halo tile
+ * whenever W % 32 == 0 and H % 8 == 0; 0 the matrix-core gather kernel.  Bit-identical outputs (same fmaf chain). */
+int fv_set_conv0_direct(fv_ctx* ctx, int on);
 /* fv_train_step's BatchNorm backward.  0 (default): one pass per layer writes dz (the d-beta / d-gamma sums come
  * from the epilogue of the data-gradient above it).  1: no pass at all -- the weight- and data-gradient kernels of
  * the layer form dz from (g, z) while staging their operand (fv_conv2d_dgrad_fused / fv_conv2d_wgrad_fused).

@@ -183,7 +183,7 @@ def test_bn_backward_apply_from_slots(ctx, rows, C, reduced):
 
 
 @pytest.mark.parametrize('B,H,cin,cout,k,s,with_skip', [(2, 16, 32, 64, 3, 2, False), (3, 13, 64, 128, 3, 1, True), (1, 26, 256, 128, 1, 1, False),
-                                                         (2, 12, 3, 32, 3, 1, False), (4, 13, 512, 1024, 3, 1, True)])
+                                                         (2, 12, 3, 32, 3, 1, False), (2, 64, 3, 32, 3, 1, False), (4, 13, 512, 1024, 3, 1, True)])
 def test_conv_slots_then_bn_act(ctx, B, H, cin, cout, k, s, with_skip):
     """conv forward adding its column sums to the slots, then bn_act_stats_kernel: statistics, moving
     statistics (Keras: var * n/(n-(1+eps)), momentum 0.99), scale/shift and the activated output."""
@@ -304,3 +304,37 @@ def test_fused_bn_backward_through_the_tail_split(ctx):
         ctx.set_conv_scratch(None)
     assert torch.equal(plain, ops.conv2d_dgrad(ctx, dz, w.cuda(), (H, H), s))
     assert torch.equal(split, split_ref) and not torch.equal(split, plain)
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 96, 128), (3, 8, 32)])
+def test_first_layer_direct_kernel_equals_gather_kernel(ctx, B, H, W):
+    """conv0_direct.hip (vector-FMA first layer with an LDS halo tile; taken when W % 32 == 0 and H % 8 == 0) against
+    the matrix-core gather kernel: the same k-ordered fmaf chain, so raw outputs and the fused inference epilogue are
+    bit-identical; the training statistics (other fp32 partial-sum order) agree to rounding and with float64."""
+    from face_vijnana_yolov3_amd import ops
+    from face_vijnana_yolov3_amd._lib import lib, ptr
+    x = _rand((B, H, W, 3), 91, 0.0, 1.0).cuda(); w = _rand((32, 3, 3, 3), 92, -0.5, 0.5).cuda()
+    scale = _rand((32,), 93, 0.5, 1.5).cuda(); shift = _rand((32,), 94).cuda()
+    res = {}
+    try:
+        for direct in (True, False):
+            ctx.set_conv0_direct(direct)
+            slots = ops.stat_slots(32, 'cuda')
+            wd = ops.pack_first_layer(ctx, w)
+            z = torch.empty((B, H, W, 32), dtype=torch.float32, device='cuda')
+            ctx.check(lib().fv_conv2d_forward_slots(ctx.handle, ptr(x), ptr(wd), B, H, W, 3, 32, 3, 1, ptr(z), ptr(slots), slots.shape[0]), 'slots')
+            raw = torch.empty_like(z); fused = torch.empty_like(z)
+            NULL = ops.NULL
+            ctx.check(lib().fv_conv2d_forward(ctx.handle, ptr(x), ptr(wd), B, H, W, 3, 32, 3, 1, NULL, NULL, -1.0, NULL, ptr(raw), NULL, NULL), 'raw')
+            ctx.check(lib().fv_conv2d_forward(ctx.handle, ptr(x), ptr(wd), B, H, W, 3, 32, 3, 1, ptr(scale), ptr(shift), 0.1, NULL, ptr(fused), NULL, NULL), 'fused')
+            res[direct] = (z, slots.sum(0), raw, fused)
+    finally:
+        ctx.set_conv0_direct(True)
+    for k in (0, 2, 3):
+        assert torch.equal(res[True][k], res[False][k]), k
+    zc = res[True][0].cpu().double().view(-1, 32)
+    for s_ in (res[True][1].cpu(), res[False][1].cpu()):
+        assert ((s_[0] - zc.sum(0)).abs() <= 1e-5 * zc.abs().sum(0) + 1e-6).all()
+        assert ((s_[1] - (zc * zc).sum(0)).abs() <= 1e-5 * (zc * zc).sum(0) + 1e-6).all()
+    ref = _ref_conv(x.cpu().double(), w.cpu().double(), 3, 1); bound = _ref_conv(x.cpu().double().abs(), w.cpu().double().abs(), 3, 1)
+    assert ((res[True][2].cpu().double() - ref).abs() <= 2e-6 * bound + 1e-6).all()

@@ -173,9 +173,9 @@ def test_bbox_iou_pairs_kernel_bit_exact(ctx, golden_dir, tmp_path):
     with open(gtp, 'w') as f:
         f.write('FACE_ID,FILE,SUBJECT_ID,FACE_X,FACE_Y,FACE_WIDTH,FACE_HEIGHT\n')
         for k, r in enumerate(gt):
-            f.write('%d,img_%d.jpg,1,%r,%r,%r,%r\n' % (k, k % 5, r[0], r[1], r[2], r[3]))
+            f.write('%d,img_%d.jpg,1,%r,%r,%r,%r\n' % (k, k % 5, float(r[0]), float(r[1]), float(r[2]), float(r[3])))
     with open(sol, 'w') as f:
         for k, r in enumerate(det):
-            f.write('img_%d.jpg,%r,%r,%r,%r,%r\n' % (k % 5, r[0], r[1], r[2], r[3], float(rng.uniform(0.5, 1))))
+            f.write('img_%d.jpg,%r,%r,%r,%r,%r\n' % (k % 5, float(r[0]), float(r[1]), float(r[2]), float(r[3]), float(rng.uniform(0.5, 1))))
     p1, r1, m1 = ev.cal_mAP_fd(gtp, sol, 0.5); p2, r2, m2 = ev.cal_mAP_fd(gtp, sol, 0.5, ctx)
     assert np.array_equal(p1, p2) and np.array_equal(r1, r2) and m1 == m2

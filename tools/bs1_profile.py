@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from face_vijnana_yolov3_amd.engine import Engine
 eng = Engine(0); eng.init_synthetic(seed=7)
 x = torch.rand((1,416,416,3), device='cuda')
