@@ -6,8 +6,11 @@
 // (16 scalar loads + integer divisions per thread): 0.62 ms = 1.6 TB/s.  Here a workgroup owns 8 x 32 output pixels:
 //  * the 10 x 34 x 3 input halo is staged in LDS with coalesced row loads (zero outside the image),
 //  * a thread computes 4 consecutive pixels x 8 output channels: 15 ds_read_b128 of inputs, 54 of weights ([27][32] in
-//    LDS, same address across the strips: broadcast), 864 v_fma_f32 -- the SAME k-ordered fmaf chain the matrix core
-//    performs (k = tap * 3 + channel), so the result is bit-identical to the gather kernel's,
+//    LDS, same address across the strips: broadcast), 864 v_fma_f32 in the SAME order as the fmaf chain of the matrix-core
+//    kernel (k = tap * 3 + channel, visited 0,4,1,5,2,6,3,7 inside every group of eight: conv_mfma.hip feeds k = 4h + j
+//    of a group to MFMA j from lane half h), so the result is bit-identical to the gather kernel's,
+//  * the halo of the workgroup's NEXT tile is fetched into registers before the current tile is computed and written to
+//    the second LDS buffer afterwards: the global-load latency hides behind the FMAs,
 //  * the four channel-group lanes of a pixel write 128 contiguous bytes; stores are 16 bytes wide,
 //  * training mode: per-thread column sums / sums of squares are carried over all tiles of a workgroup (persistent grid),
 //    reduced through LDS once and added to the layer's fp64 accumulator slots (conv.h stat_slots);
@@ -25,7 +28,7 @@ __global__ __launch_bounds__(256, 3) void conv0_direct_kernel(const float* __res
                                                            float* __restrict__ out, int B, int H, int W,
                                                            const float* __restrict__ scale, const float* __restrict__ shift, float leaky,
                                                            double* __restrict__ slots, int nslot) {
-    __shared__ __attribute__((aligned(16))) float halo[HR * HCP];
+    __shared__ __attribute__((aligned(16))) float halo2[2][HR * HCP];
     __shared__ __attribute__((aligned(16))) float wk[27 * 32];        // [k][n]
     __shared__ float red[2][64][33];
     const int tid = threadIdx.x;
@@ -42,18 +45,37 @@ __global__ __launch_bounds__(256, 3) void conv0_direct_kernel(const float* __res
         if (scale) { sc0 = *reinterpret_cast<const float4*>(scale + 8 * q); sc1 = *reinterpret_cast<const float4*>(scale + 8 * q + 4); }
         if (shift) { sh0 = *reinterpret_cast<const float4*>(shift + 8 * q); sh1 = *reinterpret_cast<const float4*>(shift + 8 * q + 4); }
     }
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // halo element e of this thread (e = tid + 256 j, j < 4) of a tile: global offset, or -1 outside the image
+    auto halo_fetch = [&](long long tile, float (&hv)[4]) {
         const int tw = (int)(tile % tiles_w), th = (int)((tile / tiles_w) % tiles_h), b = (int)(tile / ((long long)tiles_w * tiles_h));
         const int h0 = th * TH, w0 = tw * TW;
-        __syncthreads();                               // previous tile's readers are done (and wk is visible)
-        for (int i = tid; i < HR * HC; i += 256) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j;
             const int r = i / HC, cc = i - r * HC;
-            const int ih = h0 - 1 + r, iw3 = (w0 - 1) * 3 + cc;      // float index within the image row
+            const int ih = h0 - 1 + r, iw3 = (w0 - 1) * 3 + cc;
             float v = 0.f;
-            if ((unsigned)ih < (unsigned)H && iw3 >= 0 && iw3 < W * 3) v = x[((size_t)b * H + ih) * W * 3 + iw3];
-            halo[r * HCP + cc] = v;
+            if (i < HR * HC && (unsigned)ih < (unsigned)H && iw3 >= 0 && iw3 < W * 3) v = x[((size_t)b * H + ih) * W * 3 + iw3];
+            hv[j] = v;
         }
-        __syncthreads();
+    };
+    auto halo_store = [&](float* h, const float (&hv)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j;
+            if (i < HR * HC) { const int r = i / HC; h[r * HCP + (i - r * HC)] = hv[j]; }
+        }
+    };
+    float hv[4];
+    if ((long long)blockIdx.x < ntiles) { halo_fetch(blockIdx.x, hv); halo_store(halo2[0], hv); }
+    __syncthreads();                                   // halo of the first tile and wk are visible
+    int cur = 0;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+        const int tw = (int)(tile % tiles_w), th = (int)((tile / tiles_w) % tiles_h), b = (int)(tile / ((long long)tiles_w * tiles_h));
+        const int h0 = th * TH, w0 = tw * TW;
+        const float* halo = halo2[cur];
+        const bool more = tile + gridDim.x < ntiles;
+        if (more) halo_fetch(tile + gridDim.x, hv);    // in flight while this tile computes
         float in[3][20];   // 18 used
 #pragma unroll
         for (int dr = 0; dr < 3; ++dr)
@@ -71,12 +93,19 @@ __global__ __launch_bounds__(256, 3) void conv0_direct_kernel(const float* __res
         // scheduler hoists all 54 weight reads to the top: 256 VGPRs, one wave per SIMD)
         float4 wa = *reinterpret_cast<const float4*>(&wk[8 * q]), wb = *reinterpret_cast<const float4*>(&wk[8 * q + 4]);
 #pragma unroll
-        for (int k = 0; k < 27; ++k) {
+        for (int kk = 0; kk < 32; ++kk) {
+            // position kk of the chain -> k: inside each group of eight the order is 0,4,1,5,2,6,3,7 (see the header)
+            constexpr int ORD[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+            const int k = (kk & ~7) + ORD[kk & 7];
+            int kn = 32;                                   // next k < 27 in chain order
+#pragma unroll
+            for (int t = 31; t > kk; --t) { const int c = (t & ~7) + ORD[t & 7]; if (c < 27) kn = c; }
+            if (k >= 27) continue;                         // zero-padded K slots of the matrix-core kernel: fma(0, 0, acc) = acc
             const int tp = k / 3, ci = k - tp * 3, dr = tp / 3, dc = tp - dr * 3;
             float4 na = wa, nb = wb;
-            if (k + 1 < 27) {
-                na = *reinterpret_cast<const float4*>(&wk[(k + 1) * 32 + 8 * q]);
-                nb = *reinterpret_cast<const float4*>(&wk[(k + 1) * 32 + 8 * q + 4]);
+            if (kn < 27) {
+                na = *reinterpret_cast<const float4*>(&wk[kn * 32 + 8 * q]);
+                nb = *reinterpret_cast<const float4*>(&wk[kn * 32 + 8 * q + 4]);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -108,6 +137,8 @@ __global__ __launch_bounds__(256, 3) void conv0_direct_kernel(const float* __res
             *reinterpret_cast<float4*>(op + j * 32) = v0;
             *reinterpret_cast<float4*>(op + j * 32 + 4) = v1;
         }
+        if (more) halo_store(halo2[cur ^ 1], hv);
+        __syncthreads();                               // next halo visible; this tile's readers are done
     }
     if (epi & FV_EPI_STATS) {
         // 64 strips x 4 channel groups -> 32 columns: one LDS pass, then fp64 atomics to this workgroup's slot

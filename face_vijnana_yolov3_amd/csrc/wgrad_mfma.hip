@@ -115,10 +115,60 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
     for (int p = 0; p < AL; ++p) ra[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
     for (int p = 0; p < BL; ++p) rb[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
 #endif
+    // PREP: offsets of the next chunk computed between the MFMAs of the current one instead of in front of the chunk's first
+    // MFMA.  Measured neutral-to-slower on MI355X (tools/layer_bench.py, 7 shapes: wgrad sum 14.36 with, 14.15 ms without;
+    // without any loads 14.03, without the atomic epilogue 14.00): the per-chunk address arithmetic is not what the
+    // weight-gradient kernels wait for.  Kept behind a macro.
+#if defined(FV_WGRAD_PREP)
+    constexpr bool PREP = !GATHER;
+#else
+    constexpr bool PREP = false;
+#endif
+    unsigned offA[AL], offB[BL];
+    // prep(): byte offsets of the chunk to be loaded next (and the branch-free advance of the pixel coordinates) -- ~120 vector
+    // instructions per chunk that used to sit in front of the chunk's first MFMA; issue(): the loads themselves
+    auto prep = [&]() {
+#pragma unroll
+        for (int p = 0; p < AL; ++p) {
+            offA[p] = ((unsigned)a_m[p] * (unsigned)a.Ndy * 4u + a_off[p]) | (a_m[p] < a.M ? 0u : OOB);
+            a_m[p] += KP;
+        }
+        if constexpr (!GATHER) {
+#pragma unroll
+            for (int p = 0; p < BL; ++p) {
+                int ih = b_oh[p] * a.is + dh, iw = b_ow[p] * a.is + dw;
+                const bool ok = b_m[p] < a.M && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+                offB[p] = ((unsigned)(((b_b[p] * a.Hin + ih) * a.Win + iw) * a.Cin + c0 + b_col[p]) * 4u) | (ok ? 0u : OOB);
+                b_m[p] += KP;
+                b_ow[p] += adv_w;
+                { const bool c = b_ow[p] >= a.Wl; b_ow[p] -= c ? a.Wl : 0; b_oh[p] += adv_h + (c ? 1 : 0); }
+                { const bool c = b_oh[p] >= a.Hl; b_oh[p] -= c ? a.Hl : 0; b_b[p] += adv_b + (c ? 1 : 0); }
+            }
+        }
+    };
+    auto pin_offsets = [&]() {
+#pragma unroll
+        for (int p = 0; p < AL; ++p) asm volatile("" : "+v"(offA[p]));
+#pragma unroll
+        for (int p = 0; p < BL; ++p) asm volatile("" : "+v"(offB[p]));
+    };
+    auto issue = [&]() {
+#if defined(FV_ABLATE_NOLOAD)
+        return;
+#endif
+#pragma unroll
+        for (int p = 0; p < AL; ++p) {
+            ra[p] = __builtin_amdgcn_raw_buffer_load_b128(yr, offA[p], 0, 0);
+            if constexpr (VIRT) { rz[p] = __builtin_amdgcn_raw_buffer_load_b128(zr, offA[p], 0, 0); st_ok[p] = (offA[p] & OOB) == 0; }
+        }
+#pragma unroll
+        for (int p = 0; p < BL; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, offB[p], 0, 0);
+    };
     auto load = [&]() {
 #if defined(FV_ABLATE_NOLOAD)
         return;
 #endif
+        if constexpr (PREP) { issue(); return; }
 #pragma unroll
         for (int p = 0; p < AL; ++p) {
             // a_off carries the OOB bit for channel groups outside N; rows past M get it here (no branches)
@@ -215,10 +265,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     };
 
+    if constexpr (PREP) prep();
     load();
 #pragma unroll
     for (int p = 0; p < AL; ++p) transform(p);
     stage(0);
+    if constexpr (PREP) prep();     // offsets of chunk ch_begin + 1
     __syncthreads();
     constexpr int NP = KW / 2;   // k-pairs per chunk for this wave
     // the next chunk is staged mid-chunk; with the fused operand its rows are transformed one per k-pair pair before that
@@ -236,6 +288,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
             readfrag(As[cur], Bs[cur], 2 * (i + 1), af1, bf1);
             __builtin_amdgcn_sched_barrier(0);
             mfma(af0, bf0);
+            if constexpr (PREP) {
+                if (i == (QUAD ? 12 : 0)) {   // after this chunk's loads were issued and (QUAD) after the staging of the next one
+                    prep();
+#pragma unroll
+                    for (int q = 0; q < MB * NB; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                    }
+                    pin_offsets();
+                }
+            }
             if constexpr (VIRT) {
                 if (QUAD ? (i >= 2 && i <= 8) : (i == IS)) {
                     if constexpr (QUAD) transform((i - 2) / 2);
@@ -263,6 +326,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
         __syncthreads();
     }
 
+#if defined(FV_ABLATE_NOATOMIC)
+    if (acc[0][0][0] != 12345.678f) return;   // ablation: no accumulation epilogue (keeps the MFMAs alive)
+#endif
     const int half = lane >> 5, lc = lane & 31;
     const int Kw = GATHER ? 9 * a.Cin : 0;
 #pragma unroll

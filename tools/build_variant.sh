@@ -10,7 +10,7 @@ out=$root/tools/_variants; obj=$out/obj_$name
 mkdir -p "$obj"
 pids=()
 for s in "$root"/face_vijnana_yolov3_amd/csrc/*.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off "$@" -c "$s" -o "$obj/$(basename "${s%.hip}").o" 2>/dev/null &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-slp-vectorize "$@" -c "$s" -o "$obj/$(basename "${s%.hip}").o" 2>/dev/null &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done

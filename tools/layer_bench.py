@@ -46,7 +46,7 @@ def main():
     print('%-28s %5s | %8s %7s | %8s %7s | %8s %7s' % ('k s cin cout H', 'count', 'fwd ms', 'TF', 'dgrad ms', 'TF', 'wgrad ms', 'TF'))
     tot = [0.0, 0.0, 0.0]
     for (k, s, cin, cout, H), cnt in seen.items():
-        if a.only and a.only not in ('%d_%d_%d_%d' % (k, s, cin, cout)):
+        if a.only and ('%d_%d_%d_%d' % (k, s, cin, cout)) not in a.only.split(','):
             continue
         B = a.batch
         x = torch.rand((B, H, H, cin), device='cuda')
