@@ -227,7 +227,7 @@ def pmc_traffic(B, S):
             tj = json.load(open(os.path.join(ROOT, 'profiles', name)))
         except (OSError, ValueError):
             continue
-        tk = tj.get('conv_kernel<128, 2, 2, false>')
+        tk = next((v for k, v in tj.items() if k.startswith('conv_kernel<128, 2, 2, false')), None)   # (+ later template flags)
         if not tk or B != PER_GPU_BATCH or S != IMAGE_SIZE:
             return None, None
         if tj.get('_source_fingerprint') != source_fingerprint():
