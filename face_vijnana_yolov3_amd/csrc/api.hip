@@ -66,6 +66,12 @@ int fv_set_tail_split(fv_ctx* ctx, int on) {
     return FV_OK;
 }
 
+int fv_set_conv_waves8(fv_ctx* ctx, int on) {
+    if (!ctx) return FV_ERR_INVALID;
+    ctx->conv_waves8 = on != 0;
+    return FV_OK;
+}
+
 int fv_set_conv0_direct(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;
     ctx->conv0_direct = on != 0;
@@ -134,6 +140,7 @@ int fv_create(int device, void* stream, fv_ctx** out) {
                        prop.gcnArchName);
     fv_ctx* c = new fv_ctx();
     c->device = device;
+    if (const char* e = getenv("FV_CONV_WAVES8")) c->conv_waves8 = e[0] != '0';
     c->stream = (hipStream_t)stream;
     // The side stream carries the weight-gradient kernels of the backward overlap at the LOWEST stream priority:
     // the dispatcher then serves the data-gradient / BN-backward chain (the critical path) first and the weight

@@ -54,16 +54,34 @@ struct BnRedAcc {
         gy = (z.w * sc.w + sh.w) > 0.f ? g.w : g.w * leaky; db.w += gy; dg.w += gy * ((z.w - mu.w) * is.w);
     }
 };
-// reduce the per-thread sums over the RL row lanes through LDS (scratch: 2 * RL * BN floats) and add the
-// tile's column sums to slot `row_id % nslot`
+// reduce the per-thread sums over the row lanes through LDS (scratch: 2 * RL * BN floats) and add the tile's column sums to
+// slot `row_id % nslot`.  With more than 256 threads the two row lanes that share a wave (lanes l and l ^ 32 hold the same
+// four columns when BN = 128) are combined by a shuffle first, so that the scratch still fits behind the output tile.
 template <int BN, int NTH>
 __device__ __forceinline__ void bnred_flush(const FvConvArgs& a, const BnRedAcc& r, float* scratch, int n0, int row_id) {
-    constexpr int C4 = BN / 4, RL = NTH / C4;
-    const int tid = threadIdx.x, c4 = (tid % C4) * 4, rl = tid / C4;
+    constexpr int C4 = BN / 4;
+    constexpr bool PAIR = NTH > 256;          // pre-reduce the row lanes that share a wave: one scratch row per wave
+    static_assert(!PAIR || (64 % C4 == 0), "the in-wave pre-reduction needs the column groups to tile a wave");
+    constexpr int RL = PAIR ? NTH / 64 : NTH / C4;
+    const int tid = threadIdx.x, c4 = (tid % C4) * 4;
+    float4 db = r.db, dg = r.dg;
+    int rl = tid / C4;
+    bool writer = true;
+    if constexpr (PAIR) {
+#pragma unroll
+        for (int o = C4; o < 64; o <<= 1) {   // lanes l and l ^ o hold the same four columns
+            db.x += __shfl_xor(db.x, o); db.y += __shfl_xor(db.y, o); db.z += __shfl_xor(db.z, o); db.w += __shfl_xor(db.w, o);
+            dg.x += __shfl_xor(dg.x, o); dg.y += __shfl_xor(dg.y, o); dg.z += __shfl_xor(dg.z, o); dg.w += __shfl_xor(dg.w, o);
+        }
+        writer = (tid & 63) < C4;
+        rl = tid >> 6;
+    }
     float (*red)[RL][BN] = reinterpret_cast<float (*)[RL][BN]>(scratch);
     __syncthreads();
-    *reinterpret_cast<float4*>(&red[0][rl][c4]) = r.db;
-    *reinterpret_cast<float4*>(&red[1][rl][c4]) = r.dg;
+    if (writer) {
+        *reinterpret_cast<float4*>(&red[0][rl][c4]) = db;
+        *reinterpret_cast<float4*>(&red[1][rl][c4]) = dg;
+    }
     __syncthreads();
     if (tid < BN && n0 + tid < a.Nout) {
         float s = 0.f, q = 0.f;
@@ -91,16 +109,21 @@ __device__ __forceinline__ void stat_store(const FvConvArgs& a, int mt, int n, f
 }
 
 template <int BN, int WAVES_M, int WAVES_N, bool GATHER, bool VIRT = false>
-__global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const FvConvArgs a) {
+    // NTH threads: 4 waves (2x2, each 64x64) or 8 waves (2x4, each 64x32: two more waves per SIMD to cover barriers and LDS latency)
+    constexpr int NTH = 64 * WAVES_M * WAVES_N;
+    constexpr int APT = BM * 8 / NTH;      // A-tile float4 loads per thread
+    constexpr int RSTEP = NTH / 8;         // tile rows covered by one pass of the workgroup
+    static_assert(!(GATHER || VIRT) || NTH == 256, "gather / fused-operand paths are written for 4 waves");
     static_assert(!(GATHER && VIRT), "the gathered first layer has no data-gradient");
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int MB = WTM / 32, NB = WTN / 32;
-    constexpr int BL = BN / 32;  // B-tile float4 loads per thread
-    static_assert(WAVES_M * WAVES_N == 4 && MB >= 1 && NB >= 1, "bad tiling");
+    constexpr int BL = BN * 8 / NTH;  // B-tile float4 loads per thread
+    static_assert((NTH == 256 || NTH == 512) && MB >= 1 && NB >= 1 && BL >= 1, "bad tiling");
 
     // one block: A double buffer, B double buffer; reused as the BM x BN output tile by the epilogue
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDT];
-    static_assert(2 * (BM + BN) * LDT >= BM * BN + 2 * (256 / (BN / 4)) * BN, "operand LDS must hold the output tile + the BN-backward reduction scratch");
+    static_assert(2 * (BM + BN) * LDT >= BM * BN + 2 * (NTH > 256 ? NTH / 64 : NTH / (BN / 4)) * BN, "operand LDS must hold the output tile + the BN-backward reduction scratch");
     float (*As)[BM * LDT] = reinterpret_cast<float (*)[BM * LDT]>(smem);
     float (*Bs)[BN * LDT] = reinterpret_cast<float (*)[BN * LDT]>(smem + 2 * BM * LDT);
     __shared__ int rowoff[BM];
@@ -205,10 +228,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
             (void*)a.w, 0, (int)((unsigned)a.Nout * a.Tw * a.Cin * 4u), 0x00020000);
         const int col4 = (tid & 7) * 4;
-        int a_pix[4], a_oh[4], a_ow[4];
+        int a_pix[APT], a_oh[APT], a_ow[APT];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int m = m0 + (tid >> 3) + 32 * p;
+        for (int p = 0; p < APT; ++p) {
+            int m = m0 + (tid >> 3) + RSTEP * p;
             if (m < a.M) {
                 int b = m / HWl, rem = m - b * HWl, oh = rem / a.Wl, ow = rem - oh * a.Wl;
                 a_pix[p] = b * a.Hin; a_oh[p] = oh * a.is; a_ow[p] = ow * a.is;
@@ -219,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
         unsigned b_row[BL];
 #pragma unroll
         for (int p = 0; p < BL; ++p) {
-            int n = n0 + (tid >> 3) + 32 * p;
+            int n = n0 + (tid >> 3) + RSTEP * p;
             b_row[p] = n < a.Nout ? (unsigned)(n * a.Tw * a.Cin + col4) * 4u : OOB;
         }
 
@@ -231,9 +254,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
         const int per = (nk + nslice - 1) / nslice;
         const int s_begin = (tail_part ? tail_q % a.tail_f : (int)blockIdx.y) * per;
         const int s_end = min(nk, s_begin + per);
-        u32x4 ra[4], rb[BL];
+        u32x4 ra[APT], rb[BL];
 #if defined(FV_ABLATE_NOLOAD)
-        for (int p = 0; p < 4; ++p) ra[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
+        for (int p = 0; p < APT; ++p) ra[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
         for (int p = 0; p < BL; ++p) rb[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
 #endif
         // VIRT: x is g; the matching z rows and this K step's six per-channel vectors travel with the operand loads and the
@@ -243,13 +266,13 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
         u32x4 rz[VIRT ? 4 : 1];
         FvVirtVec vv;
         float4 tv[VIRT ? 4 : 1];   // transformed rows, formed between the MFMAs of chunks 1-2, written to LDS by stage()
-        unsigned st_off[4];        // a_off of the loaded step
-        unsigned a_off[4];
+        unsigned st_off[APT];      // a_off of the loaded step
+        unsigned a_off[APT];
         int t = s_begin / cpk, ci = s_begin - t * cpk;
         auto set_tap = [&](int tp) {
             const int dh = taps.dh[tp], dw = taps.dw[tp];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
+            for (int p = 0; p < APT; ++p) {
                 int ih = a_oh[p] + dh, iw = a_ow[p] + dw;
                 bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
                 a_off[p] = ok ? (unsigned)(((a_pix[p] + ih) * a.Win + iw) * a.Cin + col4) * 4u : OOB;
@@ -267,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
             const int wofs = (taps.wslot[t] * a.Cin) * 4 + c0b;
 #endif
 #pragma unroll
-            for (int p = 0; p < 4; ++p) ra[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, a_off[p], c0b, 0);
+            for (int p = 0; p < APT; ++p) ra[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, a_off[p], c0b, 0);
             if constexpr (VIRT) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) { rz[p] = __builtin_amdgcn_raw_buffer_load_b128(zr, a_off[p], c0b, 0); st_off[p] = a_off[p]; }
@@ -295,12 +318,12 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
                     *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * p) * LDT + col4]) = tv[p];
             } else {
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-                *reinterpret_cast<u32x4*>(&As[buf][((tid >> 3) + 32 * p) * LDT + col4]) = ra[p];
+            for (int p = 0; p < APT; ++p)
+                *reinterpret_cast<u32x4*>(&As[buf][((tid >> 3) + RSTEP * p) * LDT + col4]) = ra[p];
             }
 #pragma unroll
             for (int p = 0; p < BL; ++p)
-                *reinterpret_cast<u32x4*>(&Bs[buf][((tid >> 3) + 32 * p) * LDT + col4]) = rb[p];
+                *reinterpret_cast<u32x4*>(&Bs[buf][((tid >> 3) + RSTEP * p) * LDT + col4]) = rb[p];
         };
         auto advance = [&]() {
 #if defined(FV_ABLATE_SAMEADDR)
@@ -407,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
         __syncthreads();
         float4* dst = reinterpret_cast<float4*>(a.tail_slab + (size_t)tail_q * (BM * BN));
 #pragma unroll
-        for (int p = 0; p < BM * BN / 4 / 256; ++p) dst[tid + 256 * p] = reinterpret_cast<const float4*>(Cs)[tid + 256 * p];
+        for (int p = 0; p < BM * BN / 4 / NTH; ++p) dst[tid + NTH * p] = reinterpret_cast<const float4*>(Cs)[tid + NTH * p];
         return;
     }
     if (a.epi & FV_EPI_STATS) {
@@ -448,11 +471,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
         constexpr int C4 = BN / 4;                   // float4 pieces per tile row
         float* outp = a.out + (size_t)blockIdx.y * a.split_stride;
         const bool bnred = (a.epi & FV_EPI_BNRED) != 0;
-        BnRedAcc br;                                 // 256 % C4 == 0: a thread keeps its 4 columns over the rows
+        BnRedAcc br;                                 // NTH % C4 == 0: a thread keeps its 4 columns over the rows
         br.init(a, n0 + (tid % C4) * 4, bnred && n0 + (tid % C4) * 4 < a.Nout);
 #pragma unroll
-        for (int p = 0; p < BM * C4 / 256; ++p) {
-            const int f = tid + 256 * p, row = f / C4, c4 = (f % C4) * 4;
+        for (int p = 0; p < BM * C4 / NTH; ++p) {
+            const int f = tid + NTH * p, row = f / C4, c4 = (f % C4) * 4;
             const int off = rowoff[row], n = n0 + c4;
             if (off >= 0 && n < a.Nout) {
                 float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -474,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const FvConvArgs a) {
                 if (bnred) br.add(v, zv, a.bn_leaky);
             }
         }
-        if (bnred) bnred_flush<BN, 256>(a, br, smem + BM * BN, n0, mt + cls * (int)(gridDim.x / NT));
+        if (bnred) bnred_flush<BN, NTH>(a, br, smem + BM * BN, n0, mt + cls * (int)(gridDim.x / NT));
         return;
     }
     // scalar path: output rows that are not 16-byte aligned (head: 6 channels; 255-channel detection convs)
@@ -783,6 +806,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel_dma(const FvConvArgs a) {
 
 template <int BN, int WM_, int WN_, bool G, bool V = false>
 int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
+    constexpr int NTH = 64 * WM_ * WN_;
     const int MT = (a.M + BM - 1) / BM, NT = (a.Nout + BN - 1) / BN;
     dim3 grid(MT * NT, a.ksplit > 1 ? a.ksplit : 1, a.nclass);
     // (the BN-backward-applying instantiations are timed under the same names: same tiles, same role in the step)
@@ -810,7 +834,7 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
             if (tf > 1 && need <= ctx->tail_slab_floats) {
                 b.tail_f = tf; b.tail_full = full; b.tail_slab = ctx->tail_slab;
                 const int R = MT * NT - full;
-                hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G, V>), dim3(full + R * tf, 1, 1), dim3(256), 0, ctx->stream, b);
+                hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G, V>), dim3(full + R * tf, 1, 1), dim3(NTH), 0, ctx->stream, b);
                 FV_LAUNCH_CHECK(ctx);
                 hipLaunchKernelGGL((conv_tail_fixup_kernel<BN>), dim3(R), dim3(1024), 0, ctx->stream, b);
                 FV_LAUNCH_CHECK(ctx);
@@ -818,7 +842,7 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
             }
         }
     }
-    hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G, V>), grid, dim3(256), 0, ctx->stream, b);
+    hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G, V>), grid, dim3(NTH), 0, ctx->stream, b);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }
@@ -900,7 +924,9 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
         if (a.Nout > 32) return launch_cfg<64, 2, 2, false, true>(ctx, a);
         return launch_cfg<32, 4, 1, false, true>(ctx, a);
     }
-    if (a.Nout > 64) return launch_cfg<128, 2, 2, false>(ctx, a);
-    if (a.Nout > 32) return launch_cfg<64, 2, 2, false>(ctx, a);
+    // 128-wide tiles: 8 waves (2 x 4, each 64 x 32) put four waves on every SIMD instead of two: the same per-element fmaf
+    // chain (bit-identical outputs), 129 against 121 TF on the 52x52 layers; the LDS-DMA variant is written for 4 waves
+    if (a.Nout > 64) return ctx->conv_waves8 && !ctx->conv_dma ? launch_cfg<128, 2, 4, false>(ctx, a) : launch_cfg<128, 2, 2, false>(ctx, a);
+    if (a.Nout > 32) return ctx->conv_waves8 && !ctx->conv_dma ? launch_cfg<64, 4, 2, false>(ctx, a) : launch_cfg<64, 2, 2, false>(ctx, a);
     return launch_cfg<32, 4, 1, false>(ctx, a);
 }

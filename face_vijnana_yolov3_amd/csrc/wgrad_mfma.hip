@@ -23,19 +23,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KP = 32;  // pixels per chunk
 
-template <int TM, int TN, bool QUAD, bool GATHER, bool VIRT = false>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int nsplit, int ntap_eff, int tiles_taps, int pinned) {
+// NW = 8 (QUAD only): 512-thread workgroups, 2 x 4 waves of 64 x 32 -- four waves per SIMD instead of two, same arithmetic.
+template <int TM, int TN, bool QUAD, bool GATHER, bool VIRT = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, int nsplit, int ntap_eff, int tiles_taps, int pinned) {
+    static_assert(NW == 4 || (NW == 8 && QUAD && !GATHER), "8 waves: the 128x128 form only");
+    constexpr int NTH = 64 * NW;
     constexpr int LDA = TM + 4, LDB = TN + 4;  // +4 keeps 16-byte row alignment for the staged float4 writes
-    constexpr int WTM = QUAD ? TM / 2 : TM, WTN = QUAD ? TN / 2 : TN;
+    constexpr int WTM = QUAD ? TM / 2 : TM, WTN = QUAD ? TN / (NW / 2) : TN;
     constexpr int MB = WTM / 32, NB = WTN / 32;
-    constexpr int AL = TM * KP / 4 / 256, BL = TN * KP / 4 / 256;  // float4 loads per thread (>=1)
-    static_assert(AL >= 1 && BL >= 1, "tile too small for 256 threads");
+    constexpr int AL = TM * KP / 4 / NTH, BL = TN * KP / 4 / NTH;  // float4 loads per thread (>=1)
+    static_assert(AL >= 1 && BL >= 1, "tile too small for the workgroup");
 
     __shared__ __attribute__((aligned(16))) float As[2][KP * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][KP * LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = QUAD ? (wave >> 1) : 0, wn = QUAD ? (wave & 1) : 0;
+    const int wm = QUAD ? wave / (NW / 2) : 0, wn = QUAD ? wave % (NW / 2) : 0;
     const int NTc = GATHER ? 1 : a.Cin / TN;
     // Workgroup ids go round-robin over the 8 XCDs (one L2 each).  All (tile, tap) workgroups of one
     // K-split read the same 32-pixel chunks of x and dy, so a split is pinned to one XCD: id = 8 j + xcd,
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
     int a_m[AL];
 #pragma unroll
     for (int p = 0; p < AL; ++p) {
-        int f = tid + 256 * p, row = f / (TM / 4), col = (f % (TM / 4)) * 4;
+        int f = tid + NTH * p, row = f / (TM / 4), col = (f % (TM / 4)) * 4;
         a_m[p] = ch_begin * KP + row;
         a_off[p] = (n0 + col < a.N) ? (unsigned)(n0 + col) * 4u : OOB;
     }
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
     if constexpr (!GATHER) {
 #pragma unroll
         for (int p = 0; p < BL; ++p) {
-            int f = tid + 256 * p, row = f / (TN / 4);
+            int f = tid + NTH * p, row = f / (TN / 4);
             b_col[p] = (f % (TN / 4)) * 4;
             int m = ch_begin * KP + row;
             b_m[p] = m;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
     auto stage = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < AL; ++p) {
-            int f = tid + 256 * p, row = f / (TM / 4), col = (f % (TM / 4)) * 4;
+            int f = tid + NTH * p, row = f / (TM / 4), col = (f % (TM / 4)) * 4;
             if constexpr (VIRT) *reinterpret_cast<float4*>(&As[buf][row * LDA + col]) = tv[p];
             else *reinterpret_cast<u32x4*>(&As[buf][row * LDA + col]) = ra[p];
         }
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const FvWgradArgs a, int 
         } else {
 #pragma unroll
             for (int p = 0; p < BL; ++p) {
-                int f = tid + 256 * p, row = f / (TN / 4), col = (f % (TN / 4)) * 4;
+                int f = tid + NTH * p, row = f / (TN / 4), col = (f % (TN / 4)) * 4;
                 *reinterpret_cast<u32x4*>(&Bs[buf][row * LDB + col]) = rb[p];
             }
         }
@@ -386,7 +389,12 @@ int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
     const int nsplit8 = pinned ? (nsplit + 7) / 8 * 8 : nsplit;   // padded splits return at once (no chunks)
     if (a.virt.z)
         hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER, true>), dim3(tiles * nsplit8), dim3(256), 0, ctx->stream, a, nsplit, ntap, tiles, pinned);
-    else
+    else if constexpr (QUAD) {
+        if (ctx->conv_waves8)
+            hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER, false, 8>), dim3(tiles * nsplit8), dim3(512), 0, ctx->stream, a, nsplit, ntap, tiles, pinned);
+        else
+            hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER>), dim3(tiles * nsplit8), dim3(256), 0, ctx->stream, a, nsplit, ntap, tiles, pinned);
+    } else
         hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER>), dim3(tiles * nsplit8), dim3(256), 0, ctx->stream, a, nsplit, ntap, tiles, pinned);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;

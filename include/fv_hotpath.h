@@ -57,6 +57,10 @@ int fv_set_conv_dma(fv_ctx* ctx, int on);
  * fix-up kernel sums in fixed slice order before the epilogue.  Deterministic; changes only the
  * fp32 summation order of those tiles (default: on). */
 int fv_set_tail_split(fv_ctx* ctx, int on);
+/* 128-wide conv tiles (forward and data-gradient of every layer with >= 128 output channels): 1 (default) 512-thread
+ * workgroups, 8 waves of 64x32 -- four waves per SIMD cover each other's barriers and LDS latency; 0: 256 threads,
+ * 4 waves of 64x64.  Same k-ordered fmaf chain per output element: bit-identical results. */
+int fv_set_conv_waves8(fv_ctx* ctx, int on);
 /* First layer (3 -> 32 channels, K = 27, HBM-bound): 1 (default) a direct vector-FMA kernel with an LDS halo tile
  * whenever W % 32 == 0 and H % 8 == 0; 0 the matrix-core gather kernel.  Bit-identical outputs (same fmaf chain). */
 int fv_set_conv0_direct(fv_ctx* ctx, int on);

@@ -281,7 +281,10 @@ def test_fused_bn_backward_operand_equals_the_separate_pass(ctx, B, H, cin, cout
     dx_a = ops.conv2d_dgrad_fused(ctx, gd, zd, vecs, w.cuda(), (H, H), s, addend=add, bnred=(z2, *v2, s_a))
     dx_b = ops.conv2d_dgrad_bnred(ctx, dz, w.cuda(), (H, H), s, z2, *v2, s_b, addend=add)
     assert torch.equal(dx_a, dx_b)
-    torch.testing.assert_close(s_a.sum(0), s_b.sum(0), rtol=1e-12, atol=1e-9)     # same per-tile sums, fp64 atomic order only
+    # same gy values; the fp32 partial sums over a tile's rows are formed in another order by the 4-wave (fused) and the
+    # 8-wave (plain) kernel: agreement to float32 rounding of the column sums
+    mag = s_b.sum(0).abs().max().item()
+    torch.testing.assert_close(s_a.sum(0), s_b.sum(0), rtol=2e-5, atol=2e-5 * mag)
 
 
 def test_fused_bn_backward_through_the_tail_split(ctx):
@@ -338,3 +341,40 @@ def test_first_layer_direct_kernel_equals_gather_kernel(ctx, B, H, W):
         assert ((s_[1] - (zc * zc).sum(0)).abs() <= 1e-5 * (zc * zc).sum(0) + 1e-6).all()
     ref = _ref_conv(x.cpu().double(), w.cpu().double(), 3, 1); bound = _ref_conv(x.cpu().double().abs(), w.cpu().double().abs(), 3, 1)
     assert ((res[True][2].cpu().double() - ref).abs() <= 2e-6 * bound + 1e-6).all()
+
+
+@pytest.mark.parametrize('B,H,cin,cout,k,s', [(2, 16, 128, 256, 3, 1), (3, 12, 128, 128, 3, 2), (2, 13, 256, 128, 1, 1), (2, 140, 256, 128, 3, 1),
+                                            (2, 16, 64, 128, 3, 1), (2, 16, 32, 64, 3, 2), (3, 13, 64, 64, 1, 1)])
+def test_eight_wave_conv_equals_four_wave_conv(ctx, B, H, cin, cout, k, s):
+    """fv_set_conv_waves8: 512-thread workgroups (8 waves of 64x32) against 256-thread ones (4 waves of 64x64) on the
+    128- and 64-wide tiles.  Every output element is the same k-ordered fmaf chain: forward (raw, fused epilogue, BN partial
+    sums) and data-gradient are bit-identical; the fused BN-backward column sums agree to float32 rounding (the two
+    row lanes of a wave are pre-added by a shuffle in the 8-wave form).  The last shape takes the tail split."""
+    from face_vijnana_yolov3_amd import ops
+    x = _rand((B, H, H, cin), 111).cuda(); w = _rand((cout, k, k, cin), 112, -0.2, 0.2).cuda()
+    Ho = H // s
+    dy = _rand((B, Ho, Ho, cout), 113).cuda(); add = _rand((B, H, H, cin), 114).cuda()
+    z2 = _rand((B, H, H, cin), 115, -2.0, 2.0).cuda(); v2 = [v.cuda() for v in _bn_vectors(cin, 116)]
+    scale = _rand((cout,), 117, 0.5, 1.5).cuda(); shift = _rand((cout,), 118).cuda()
+    res = {}
+    if H == 140:
+        ctx.set_conv_scratch(torch.empty(64 << 20, dtype=torch.uint8, device='cuda'))
+    try:
+        for w8 in (True, False):
+            ctx.set_conv_waves8(w8)
+            out, psum, psq = ops.conv2d_forward(ctx, x, w, stride=s, stats=True)
+            fused = ops.conv2d_forward(ctx, x, w, s, scale, shift, 0.1, None)
+            slots = ops.stat_slots(cin, 'cuda')
+            dx = ops.conv2d_dgrad_bnred(ctx, dy, w, (H, H), s, z2, *v2, slots, addend=add)
+            res[w8] = (out, psum, psq, fused, dx, slots.sum(0))
+    finally:
+        ctx.set_conv_waves8(True); ctx.set_conv_scratch(None)
+    for i in range(5):
+        if i in (1, 2) and cout <= 64:
+            # 64-wide tiles: the 8-wave form is 4 x 2 waves (32 rows each) against 2 x 2 (64 rows each) -- the per-tile column
+            # sums are added up in another order; equal to float32 rounding of the sums
+            torch.testing.assert_close(res[True][i].sum(0), res[False][i].sum(0), rtol=2e-5, atol=2e-5 * res[False][i].sum(0).abs().max().item())
+            continue
+        assert torch.equal(res[True][i], res[False][i]), i
+    mag = res[False][5].abs().max().item()
+    torch.testing.assert_close(res[True][5], res[False][5], rtol=2e-5, atol=2e-5 * mag)

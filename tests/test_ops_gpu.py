@@ -297,16 +297,19 @@ def test_lds_dma_variant_is_bit_identical(ctx, B, H, cin, cout, k, s):
     so the result (incl. zero padding at the borders and the BN partials) is bit-identical."""
     from face_vijnana_yolov3_amd import ops
     x = _rand((B, H, H, cin), 71).cuda(); w = _rand((cout, k, k, cin), 72).cuda()
-    ref = ops.conv2d_forward(ctx, x, w, stride=s, stats=True)
-    ctx.set_conv_dma(True)
+    ctx.set_conv_waves8(False)          # the LDS-DMA variant is the 4-wave tiling: compare like with like (BN partial sums included)
     try:
-        got = ops.conv2d_forward(ctx, x, w, stride=s, stats=True)
+        ref = ops.conv2d_forward(ctx, x, w, stride=s, stats=True)
         dy = _rand((B, H // s, H // s, max(32, cout)), 73).cuda()
         if cout < 32:
             dy[..., cout:] = 0
+        dg_ref = ops.conv2d_dgrad(ctx, dy, w, (H, H), s)
+        ctx.set_conv_dma(True)
+        got = ops.conv2d_forward(ctx, x, w, stride=s, stats=True)
         dg = ops.conv2d_dgrad(ctx, dy, w, (H, H), s)
     finally:
-        ctx.set_conv_dma(False)
+        ctx.set_conv_dma(False); ctx.set_conv_waves8(True)
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
-    assert torch.equal(dg, ops.conv2d_dgrad(ctx, dy, w, (H, H), s))
+    assert torch.equal(dg, dg_ref)
+    assert torch.equal(ops.conv2d_forward(ctx, x, w, stride=s), ref[0])      # and the default 8-wave form: same outputs
