@@ -254,6 +254,29 @@ class BatchFeeder(object):
         self.pool = ThreadPoolExecutor(max_workers=max(1, threads))
         self.one = ThreadPoolExecutor(max_workers=1)
         self.pending = None
+        # three pinned staging buffers, reused round-robin (allocating ~100 MB of pinned memory per batch costs more than
+        # decoding it); a buffer is rewritten only after the H2D copy that read it has completed (event recorded by the consumer)
+        self._pins = [None, None, None]
+        self._pin_events = [None, None, None]
+        self._pin_next = 0
+
+    def _pinned(self, nbytes):
+        import torch
+        i = self._pin_next
+        self._pin_next = (i + 1) % 3
+        if self._pin_events[i] is not None:
+            self._pin_events[i].synchronize()
+            self._pin_events[i] = None
+        if self._pins[i] is None or self._pins[i].numel() < nbytes:
+            self._pins[i] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+        return i, self._pins[i][:nbytes]
+
+    def copied(self, slot):
+        """Called by the consumer right after it enqueued the H2D copy of the buffer in `slot`."""
+        import torch
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pin_events[slot] = ev
 
     def load(self, index):
         import torch
@@ -275,9 +298,11 @@ class BatchFeeder(object):
             for im in ims:
                 w, h = im.size
                 hw += [h, w]; offs.append(o); o += h * w * 3
-            buf = torch.empty(o, dtype=torch.uint8)
+            slot = None
             if pin:
-                buf = buf.pin_memory()
+                slot, buf = self._pinned(o)
+            else:
+                buf = torch.empty(o, dtype=torch.uint8)
             view = buf.numpy()
 
             def work(i):
@@ -288,13 +313,14 @@ class BatchFeeder(object):
             packed = (buf, offs, hw)
             shapes = [(hw[2 * i], hw[2 * i + 1]) for i in range(len(ims))]
         else:
+            slot = None
             raws = list(self.pool.map(lambda nm: seq.loader(os.path.join(seq.raw_data_path, nm)), mine))
             packed = pack_images(raws, pin=pin)
             shapes = [(r.shape[0], r.shape[1]) for r in raws]
         y = np.asarray([data.encode_gt(seq.groups[nm].iloc[:, 3:7].values, h, w, seq.image_size, seq.grid,
                                        seq.nn_arch['bb_info_c_size']) for nm, (h, w) in zip(mine, shapes)], np.float32)
         yt = torch.from_numpy(y)
-        return packed, (yt.pin_memory() if pin else yt), weight
+        return packed, (yt.pin_memory() if pin else yt), weight, (self, slot)
 
     def prefetch(self, index):
         self.pending = self.one.submit(self.load, index)
@@ -309,8 +335,10 @@ class BatchFeeder(object):
 def train_on_item(engine, trainer, item, image_size, hp):
     """One optimisation step on what BatchFeeder.load returned: H2D copy, device letterbox, fv_train_step
     (+ gradient all-reduce when world > 1), Adam."""
-    packed, y, weight = item
+    packed, y, weight, (feeder, slot) = item
     x, _ = letterbox_batch_device(engine.ctx, None, image_size, engine.dev, packed=packed)
+    if slot is not None:
+        feeder.copied(slot)
     return trainer.train_on_batch(x, y.to(engine.dev, non_blocking=True), hp['lr'], hp['beta_1'], hp['beta_2'],
                                   hp.get('decay', 0.0), weight=weight)
 
