@@ -10,8 +10,8 @@ gradients, bucketed and overlapped with backward) + Keras-formula Adam, on synth
 are already resident in HBM.  Rank 0 prints ONE JSON line.
 
 `roofline`: the dominant kernel is the 128x128-tile fp32-MFMA implicit-GEMM conv
-(conv_kernel<128,2,2,false>: forward and data-gradient of every layer with >= 128 output
-channels).  achieved = algorithmic FLOPs of its launches / their HIP-event-timed duration, taken in
+(conv_kernel<128,2,4,false>, 8 waves per workgroup: forward and data-gradient of every layer with >= 128
+output channels; conv_kernel<128,2,2,false> under fv_set_conv_waves8(0)).  achieved = algorithmic FLOPs of its launches / their HIP-event-timed duration, taken in
 instrumented steps right after the timed region (the timed steps themselves run un-instrumented).
 peak = 157.3 TFLOP/s, the dense fp32 MFMA rate of MI355X (MI355X_MICROARCH.md).
 `cpu_baseline`: the torch-CPU oracle restatement of the same step (kind "port"; the Keras/TF
@@ -37,7 +37,13 @@ IMAGE_SIZE = 416
 PER_GPU_BATCH = 40
 FP32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s is what a float4 copy reaches)
-DOMINANT = 'conv_kernel<128,2,2,false>'
+DOMINANT_RE = r'conv_kernel<128, ?2, ?[24], ?false'   # library label 'conv_kernel<128,2,4,false>' / rocprofv3 name
+
+
+def dominant(d):
+    """(key, value) of the 128-wide non-gather conv kernel in a per-kernel dict, whichever wave layout ran."""
+    import re
+    return next(((k, v) for k, v in d.items() if re.match(DOMINANT_RE, k)), (None, None))
 HPS = dict(lr=1e-4, beta_1=0.99, beta_2=0.99, decay=0.0)  # reference face_vijnana_yolov3.json:12-15
 TRAFFIC_FILES = ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 
@@ -227,7 +233,7 @@ def pmc_traffic(B, S):
             tj = json.load(open(os.path.join(ROOT, 'profiles', name)))
         except (OSError, ValueError):
             continue
-        tk = next((v for k, v in tj.items() if k.startswith('conv_kernel<128, 2, 2, false')), None)   # (+ later template flags)
+        tk = dominant(tj)[1]
         if not tk or B != PER_GPU_BATCH or S != IMAGE_SIZE:
             return None, None
         if tj.get('_source_fingerprint') != source_fingerprint():
@@ -341,14 +347,14 @@ def main():
         loader = None
         if world == 1 and not args.no_loader:
             loader = loader_bench(eng, trainer, B, S, args.loader_steps)
-        dom = prof.get(DOMINANT)
+        dom_name, dom = dominant(prof)
         roofline = None
         traffic, traffic_source = pmc_traffic(B, S)
         if dom and dom['ms'] > 0:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
             roofline = dict(bound='mfma', achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                             frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
-                            kernel=DOMINANT,
+                            kernel=dom_name,
                             algorithmic_bytes_per_launch=round(dom['bytes'] / dom['launches']),
                             mode='exclusive: instrumented steps run with fv_set_overlap(0)',
                             launches_per_step=dom['launches'] // max(args.profile_steps, 1),
@@ -373,7 +379,7 @@ def main():
             'step_frac_of_fp32_mfma_peak': round(train_flops * B * args.steps / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
             'roofline': roofline,
             'roofline_overlapped': (lambda d: None if not d or not d['ms'] else dict(
-                achieved=round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2), avg_launch_ms=round(d['ms'] / d['launches'], 4)))(prof_ov.get(DOMINANT)),
+                achieved=round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2), avg_launch_ms=round(d['ms'] / d['launches'], 4)))(dominant(prof_ov)[1]),
             # the HBM-bound companions (algorithmic bytes / HIP-event time, against the 8 TB/s HBM3E peak)
             'roofline_hbm': {k: dict(bound='hbm', achieved=v['gbps'], peak=HBM_PEAK_GBPS, unit='GB/s',
                                      frac=round(v['gbps'] / HBM_PEAK_GBPS, 4), ms_per_step=v['ms_per_step'])

@@ -16,6 +16,7 @@
 //  * epilogue: optional per-channel affine (+LeakyReLU, +residual add) for inference, or raw
 //    store + deterministic per-tile column sums / sums of squares for training-mode BatchNorm
 //  * XCD-aware bijective remap of blockIdx so tiles that share an A panel land on one L2
+#include <string>
 #include "conv.h"
 
 namespace {
@@ -810,9 +811,9 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
     const int MT = (a.M + BM - 1) / BM, NT = (a.Nout + BN - 1) / BN;
     dim3 grid(MT * NT, a.ksplit > 1 ? a.ksplit : 1, a.nclass);
     // (the BN-backward-applying instantiations are timed under the same names: same tiles, same role in the step)
-    static const char* name = BN == 128 ? (G ? "conv_kernel<128,2,2,true>" : "conv_kernel<128,2,2,false>")
-                              : BN == 64 ? (G ? "conv_kernel<64,2,2,true>" : "conv_kernel<64,2,2,false>")
-                                         : (G ? "conv_kernel<32,4,1,true>" : "conv_kernel<32,4,1,false>");
+    static const std::string name_s = "conv_kernel<" + std::to_string(BN) + "," + std::to_string(WM_) + "," + std::to_string(WN_) +
+                                      (G ? ",true>" : ",false>");   // rocprofv3's name up to the first four template arguments
+    static const char* name = name_s.c_str();
     FvProfScope ps(ctx, name, a.alg_flops,
                    4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.Nout * a.Tw * a.Cin +
                           (double)a.M * a.nclass * a.Nout * ((a.epi & FV_EPI_ADD) ? 2 : 1)));
