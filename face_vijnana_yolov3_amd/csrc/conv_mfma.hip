@@ -17,6 +17,7 @@
 //    store + deterministic per-tile column sums / sums of squares for training-mode BatchNorm
 //  * XCD-aware bijective remap of blockIdx so tiles that share an A panel land on one L2
 #include <string>
+#include <type_traits>
 #include "conv.h"
 
 namespace {
@@ -255,10 +256,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const F
         const int per = (nk + nslice - 1) / nslice;
         const int s_begin = (tail_part ? tail_q % a.tail_f : (int)blockIdx.y) * per;
         const int s_end = min(nk, s_begin + per);
+        // PD2 (the plain operand forms): the K loop is unrolled by two with two register sets -- step s issues the loads of step
+        // s + 2 into the set that was staged during step s - 1, and stages the set loaded during step s - 1.  The LDS buffer
+        // index becomes a compile-time constant and a staged row has been in its registers for a whole step.  Measured on
+        // MI355X (same box, 416x416 batch 40, ms per step of conv_kernel<128,2,4>): one set, rolled loop 28.9; one set,
+        // unrolled 28.8; this form 28.2; the same with branch-free (always issued, range-masked) loads and stores, which lets
+        // the loads of step s + 2 stay in flight across the staging point, 28.8 -- DESIGN.md 4.1.  -DFV_CONV_PD1: the rolled loop.
+#if defined(FV_CONV_PD1)
+        constexpr bool PD2 = false;
+#else
+        constexpr bool PD2 = !VIRT;
+#endif
         u32x4 ra[APT], rb[BL];
+        u32x4 ra2[PD2 ? APT : 1], rb2[PD2 ? BL : 1];
 #if defined(FV_ABLATE_NOLOAD)
         for (int p = 0; p < APT; ++p) ra[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
         for (int p = 0; p < BL; ++p) rb[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
+        for (int p = 0; p < (PD2 ? APT : 1); ++p) ra2[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
+        for (int p = 0; p < (PD2 ? BL : 1); ++p) rb2[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
 #endif
         // VIRT: x is g; the matching z rows and this K step's six per-channel vectors travel with the operand loads and the
         // staged value is dz (FvVirtDz) -- zero where the tap is outside the image (a_off == OOB), like the plain operand
@@ -333,6 +348,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const F
             if (++ci == cpk) { ci = 0; ++t; if (t < taps.n) set_tap(t); }
 #endif
         };
+        auto load2 = [&]() {      // second register set (PD2)
+#if defined(FV_ABLATE_NOLOAD)
+            return;
+#endif
+            if constexpr (PD2) {
+#if defined(FV_ABLATE_SAMEADDR)
+                const int c0b = 0;
+                const int wofs = 0;
+#else
+                const int c0b = ci * BK * 4;
+                const int wofs = (taps.wslot[t] * a.Cin) * 4 + c0b;
+#endif
+#pragma unroll
+                for (int p = 0; p < APT; ++p) ra2[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, a_off[p], c0b, 0);
+#pragma unroll
+                for (int p = 0; p < BL; ++p) rb2[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_row[p], wofs, 0);
+            }
+        };
+        auto stage2 = [&](int buf) {
+            if constexpr (PD2) {
+#pragma unroll
+                for (int p = 0; p < APT; ++p)
+                    *reinterpret_cast<u32x4*>(&As[buf][((tid >> 3) + RSTEP * p) * LDT + col4]) = ra2[p];
+#pragma unroll
+                for (int p = 0; p < BL; ++p)
+                    *reinterpret_cast<u32x4*>(&Bs[buf][((tid >> 3) + RSTEP * p) * LDT + col4]) = rb2[p];
+            }
+        };
         // fragment double-buffering: the LDS reads of K-chunk c+1 are issued before the MFMAs of
         // chunk c, and the next tile is staged into the other LDS buffer while chunks 2-3 compute
         const int arow = (wm * WTM + (lane & 31)) * LDT + (lane >> 5) * 4;
@@ -358,6 +401,42 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const F
                     }
         };
 
+        if constexpr (PD2) {
+            if (s_begin < s_end) {
+                set_tap(t);
+                load(); advance();
+                if (s_begin + 1 < s_end) { load2(); advance(); }
+                stage(0);
+            }
+            __syncthreads();
+            auto body = [&](int s, auto odd) {
+                constexpr bool ODD = decltype(odd)::value;      // even steps (from s_begin): LDS 0, next staged from set 2
+                const float* Ac = As[ODD ? 1 : 0]; const float* Bc = Bs[ODD ? 1 : 0];
+                if (s + 2 < s_end) { if constexpr (ODD) load2(); else load(); advance(); }
+                float4 af0[MB], bf0[NB], af1[MB], bf1[NB];
+                readfrag(Ac, Bc, 0, af0, bf0);
+                readfrag(Ac, Bc, 1, af1, bf1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_chunk(af0, bf0);
+                __builtin_amdgcn_sched_barrier(0);
+                readfrag(Ac, Bc, 2, af0, bf0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_chunk(af1, bf1);
+                __builtin_amdgcn_sched_barrier(0);
+                readfrag(Ac, Bc, 3, af1, bf1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_chunk(af0, bf0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < s_end) { if constexpr (ODD) stage(0); else stage2(1); }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_chunk(af1, bf1);
+                __syncthreads();
+            };
+            for (int s = s_begin; s < s_end; s += 2) {
+                body(s, std::false_type{});
+                if (s + 1 < s_end) body(s + 1, std::true_type{});
+            }
+        } else {
         if (s_begin < s_end) {
             set_tap(t);
             load();
@@ -412,6 +491,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const F
             __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(af1, bf1);
             __syncthreads();
+        }
         }
     }
 

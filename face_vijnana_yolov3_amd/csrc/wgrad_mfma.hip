@@ -15,6 +15,7 @@
 //    workgroup slots; partial tiles are added with float atomics shaped as two 128-byte row segments
 //    per wave instruction; the caller zeroes dw once per step
 //  * chunk loop: global loads one chunk ahead, LDS fragments one k-pair ahead (register double buffer)
+#include <type_traits>
 #include "conv.h"
 
 namespace {
@@ -268,6 +269,43 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     };
 
+    constexpr int NP = KW / 2;   // k-pairs per chunk for this wave
+    // U2 (plain operand forms): the chunk loop unrolled by two, so that the LDS buffer index is a compile-time constant
+    // (wgrad_kernel<128,128,quad>: 13.86 -> 13.67 ms per step on MI355X; a second register set with the loads two chunks ahead,
+    // the form the forward kernel uses, measured 13.85 with branches and 14.4 branch-free; the split forms are neutral)
+#if defined(FV_WGRAD_PREP) || defined(FV_WGRAD_ROLLED)
+    constexpr bool U2 = false;
+#else
+    constexpr bool U2 = !GATHER && !VIRT;
+#endif
+    if constexpr (U2) {
+        load();
+        stage(0);
+        __syncthreads();
+        auto body = [&](int ch, auto odd) {
+            constexpr bool ODD = decltype(odd)::value;
+            const float* Ac = As[ODD ? 1 : 0]; const float* Bc = Bs[ODD ? 1 : 0];
+            const bool more = ch + 1 < ch_end;
+            if (more) load();
+            float af0[MB], bf0[NB], af1[MB], bf1[NB];
+            readfrag(Ac, Bc, 0, af0, bf0);
+#pragma unroll
+            for (int i = 0; i < NP; i += 2) {
+                readfrag(Ac, Bc, 2 * (i + 1), af1, bf1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma(af0, bf0);
+                if (i == NP / 2) { if (more) stage(ODD ? 0 : 1); }
+                if (i + 2 < NP) readfrag(Ac, Bc, 2 * (i + 2), af0, bf0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma(af1, bf1);
+            }
+            __syncthreads();
+        };
+        for (int ch = ch_begin; ch < ch_end; ch += 2) {
+            body(ch, std::false_type{});
+            if (ch + 1 < ch_end) body(ch + 1, std::true_type{});
+        }
+    } else {
     if constexpr (PREP) prep();
     load();
 #pragma unroll
@@ -275,7 +313,6 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
     stage(0);
     if constexpr (PREP) prep();     // offsets of chunk ch_begin + 1
     __syncthreads();
-    constexpr int NP = KW / 2;   // k-pairs per chunk for this wave
     // the next chunk is staged mid-chunk; with the fused operand its rows are transformed one per k-pair pair before that
     constexpr int IS = (VIRT && QUAD) ? 10 : NP / 2;
     for (int ch = ch_begin; ch < ch_end; ++ch) {
@@ -327,6 +364,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
             mfma(af1, bf1);
         }
         __syncthreads();
+    }
     }
 
 #if defined(FV_ABLATE_NOATOMIC)
