@@ -102,6 +102,60 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
             b_b[p] = m / HWl; int rem = m - b_b[p] * HWl; b_oh[p] = rem / a.Wl; b_ow[p] = rem - b_oh[p] * a.Wl;
         }
     }
+    // SROW (128x128 form).  The 32 x rows of a chunk are 32 consecutive lattice pixels; every lane used to carry the pixel
+    // coordinates of its rows and redo the carries, the bounds test and the offset product per chunk (~70 vector instructions per
+    // lane and chunk, issued by all waves right after the barrier: the kernel ran 11 % below the same kernel with constant offsets).
+    // Now lanes 0-31 of wave 0 own one row each, advance it incrementally (KP pixels = adv_b images + adv_h rows + adv_w pixels; + K1
+    // when the column wraps, + K2 when the row wraps), and publish the masked byte offset in a 32-entry LDS table, one chunk before
+    // the loads that use it; a load's address is one LDS read plus the lane's column.  dy rows are linear in the pixel index.
+    // (Per-row arithmetic on the scalar unit was the first attempt: 60 scalar instructions per wave and chunk on the CU's single
+    // scalar pipe recovered 4.5 %.)
+#if defined(FV_WGRAD_PREP) || defined(FV_WGRAD_VROW)
+    constexpr bool SROW = false;
+#else
+    constexpr bool SROW = QUAD && !GATHER;
+#endif
+    constexpr int RPP = NTH / (TN / 4);                    // rows per pass of the workgroup
+    __shared__ unsigned rowtab[2][KP];
+    int t_oh = 0, t_ow = 0;
+    unsigned t_off = 0, tK0 = 0, tK1 = 0, tK2 = 0, lin_a[AL], lane_col = 0;
+    // row table of the chunk `rel` chunks after ch_begin -> rowtab[rel & 1]; then the producer lanes step to the next chunk
+    auto publish_rows = [&](int rel) {
+        if constexpr (SROW) {
+            if (tid < KP) {
+                const int ih = t_oh * a.is + dh, iw = t_ow * a.is + dw;
+                const bool ok = ((unsigned)ih < (unsigned)a.Hin) & ((unsigned)iw < (unsigned)a.Win);   // pixels >= M: past num_records
+                rowtab[rel & 1][tid] = ok ? t_off : OOB;
+                t_ow += adv_w;
+                const bool c1 = t_ow >= a.Wl;
+                t_ow -= c1 ? a.Wl : 0; t_oh += adv_h + (c1 ? 1 : 0);
+                const bool c2 = t_oh >= a.Hl;
+                t_oh -= c2 ? a.Hl : 0;
+                t_off += tK0 + (c1 ? tK1 : 0u) + (c2 ? tK2 : 0u);
+            }
+        }
+    };
+    if constexpr (SROW) {
+        const unsigned px = (unsigned)(a.is * a.Cin) * 4u, rowst = (unsigned)(a.is * a.Win * a.Cin) * 4u,
+                       imgst = (unsigned)(a.Hin * a.Win * a.Cin) * 4u;
+        tK0 = (unsigned)adv_b * imgst + (unsigned)adv_h * rowst + (unsigned)adv_w * px;
+        tK1 = rowst - (unsigned)a.Wl * px;
+        tK2 = imgst - (unsigned)a.Hl * rowst;
+        lane_col = (unsigned)(c0 + (lane & 31) * 4) * 4u;
+        if (tid < KP) {
+            const int m = ch_begin * KP + tid;
+            const int b = m / HWl, rem = m - b * HWl;
+            t_oh = rem / a.Wl; t_ow = rem - t_oh * a.Wl;
+            // modular: a tap above / left of the first pixel gives a "negative" offset that the bounds test masks
+            t_off = (unsigned)(((b * a.Hin + t_oh * a.is + dh) * a.Win + t_ow * a.is + dw) * a.Cin) * 4u;
+        }
+        publish_rows(0);
+        publish_rows(1);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < AL; ++p) lin_a[p] = (unsigned)a_m[p] * (unsigned)a.Ndy * 4u + a_off[p];   // rows >= M: past num_records
+    }
+    int load_rel = 0;    // chunk (relative to ch_begin) the next load() fetches
     u32x4 ra[AL], rb[BL];
     // VIRT: dy is g; the matching z rows are loaded beside it and the staged value is dz (conv.h FvVirtDz).  A thread keeps its
     // four output channels over the whole pixel loop ((tid + 256 p) % (TM / 4) does not depend on p): six vectors, loaded once
@@ -176,7 +230,9 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
 #pragma unroll
         for (int p = 0; p < AL; ++p) {
             // a_off carries the OOB bit for channel groups outside N; rows past M get it here (no branches)
-            unsigned off = ((unsigned)a_m[p] * (unsigned)a.Ndy * 4u + a_off[p]) | (a_m[p] < a.M ? 0u : OOB);
+            unsigned off;
+            if constexpr (SROW && !VIRT) { off = lin_a[p]; lin_a[p] += KP * (unsigned)a.Ndy * 4u; }
+            else off = ((unsigned)a_m[p] * (unsigned)a.Ndy * 4u + a_off[p]) | (a_m[p] < a.M ? 0u : OOB);
 #if defined(FV_ABLATE_SAMEADDR)
             off = a_off[p] != OOB ? (unsigned)(tid / (TM / 4)) * (unsigned)a.Ndy * 4u + a_off[p] : OOB;
 #endif
@@ -203,6 +259,16 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
                 }
             }
             rb[0] = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+        } else if constexpr (SROW) {
+#pragma unroll
+            for (int p = 0; p < BL; ++p) {
+                unsigned off = rowtab[load_rel & 1][RPP * p + (tid >> 5)] + lane_col;
+#if defined(FV_ABLATE_SAMEADDR)
+                off = (unsigned)((tid / (TN / 4)) * a.Cin) * 4u + lane_col;
+#endif
+                rb[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+            }
+            ++load_rel;
         } else {
 #pragma unroll
             for (int p = 0; p < BL; ++p) {
@@ -287,6 +353,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
             const float* Ac = As[ODD ? 1 : 0]; const float* Bc = Bs[ODD ? 1 : 0];
             const bool more = ch + 1 < ch_end;
             if (more) load();
+            publish_rows(ch - ch_begin + 2);
             float af0[MB], bf0[NB], af1[MB], bf1[NB];
             readfrag(Ac, Bc, 0, af0, bf0);
 #pragma unroll
@@ -319,6 +386,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
         const int cur = (ch - ch_begin) & 1;
         const bool more = ch + 1 < ch_end;
         if (more) load();
+        publish_rows(ch - ch_begin + 2);
         float af0[MB], bf0[NB], af1[MB], bf1[NB];
         readfrag(As[cur], Bs[cur], 0, af0, bf0);
 #pragma unroll
