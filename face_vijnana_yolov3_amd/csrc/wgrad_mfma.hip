@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
             b_b[p] = m / HWl; int rem = m - b_b[p] * HWl; b_oh[p] = rem / a.Wl; b_ow[p] = rem - b_oh[p] * a.Wl;
         }
     }
-    // SROW (128x128 form).  The 32 x rows of a chunk are 32 consecutive lattice pixels; every lane used to carry the pixel
+    // SROW (every form but the gathered first layer).  The 32 x rows of a chunk are 32 consecutive lattice pixels; every lane used to carry the pixel
     // coordinates of its rows and redo the carries, the bounds test and the offset product per chunk (~70 vector instructions per
     // lane and chunk, issued by all waves right after the barrier: the kernel ran 11 % below the same kernel with constant offsets).
     // Now lanes 0-31 of wave 0 own one row each, advance it incrementally (KP pixels = adv_b images + adv_h rows + adv_w pixels; + K1
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
 #if defined(FV_WGRAD_PREP) || defined(FV_WGRAD_VROW)
     constexpr bool SROW = false;
 #else
-    constexpr bool SROW = QUAD && !GATHER;
+    constexpr bool SROW = !GATHER;
 #endif
     constexpr int RPP = NTH / (TN / 4);                    // rows per pass of the workgroup
     __shared__ unsigned rowtab[2][KP];
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
         tK0 = (unsigned)adv_b * imgst + (unsigned)adv_h * rowst + (unsigned)adv_w * px;
         tK1 = rowst - (unsigned)a.Wl * px;
         tK2 = imgst - (unsigned)a.Hl * rowst;
-        lane_col = (unsigned)(c0 + (lane & 31) * 4) * 4u;
+        lane_col = (unsigned)(c0 + (tid % (TN / 4)) * 4) * 4u;      // (NTH is a multiple of TN / 4: the same column in every pass)
         if (tid < KP) {
             const int m = ch_begin * KP + tid;
             const int b = m / HWl, rem = m - b * HWl;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
         } else if constexpr (SROW) {
 #pragma unroll
             for (int p = 0; p < BL; ++p) {
-                unsigned off = rowtab[load_rel & 1][RPP * p + (tid >> 5)] + lane_col;
+                unsigned off = rowtab[load_rel & 1][RPP * p + tid / (TN / 4)] + lane_col;
 #if defined(FV_ABLATE_SAMEADDR)
                 off = (unsigned)((tid / (TN / 4)) * a.Cin) * 4u + lane_col;
 #endif
