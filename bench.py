@@ -20,6 +20,7 @@ the detect path on the CPU (oracle forward at batch 1 + the single-core C oracle
 `loader_inclusive`: the same step fed by FaceDetector.train's real input path (JPEG decode on host
 threads, one pinned H2D copy and one fv_letterbox_batch launch per batch, GT encoding) from a synthetic
 UCCS-format folder -- reported beside `value`, never as `value`.
+`three_scale_train`: one training step of the full three-scale YOLOv3 graph at batch 16 -- secondary.
 N > 1: `multi_gpu` carries per-rank all-reduce time, the exposed communication (step minus a
 compute-only step) and the RCCL world size, so that a scaling run diagnoses itself.
 """
@@ -63,6 +64,7 @@ def parse():
     ap.add_argument('--fused-bn-backward', action='store_true', help='fv_set_fused_bn_backward(1) (A/B aid; measured slower)')
     ap.add_argument('--no-detect', action='store_true', help='skip the detect-path measurement (PMC passes)')
     ap.add_argument('--no-loader', action='store_true', help='skip the loader-inclusive measurement')
+    ap.add_argument('--no-three-scale', action='store_true', help='skip the three-scale training measurement')
     ap.add_argument('--loader-steps', type=int, default=6)
     return ap.parse_args()
 
@@ -224,6 +226,40 @@ def loader_bench(eng, trainer, B, S, steps):
                      'H2D -> fv_letterbox_batch (one launch) -> fv_train_step + Adam; batch k+1 decoded while step k runs' % n_img)
 
 
+def three_scale_bench(device, S, B=16, steps=3):
+    """one training step of the full three-scale YOLOv3 graph (75 convs, two upsample+concat routes,
+    255 output channels, the build's objectness/box/class loss, Adam) -- device-resident synthetic batch.  A secondary
+    number beside `value`; this path has no side-stream overlap yet."""
+    import torch
+    from face_vijnana_yolov3_amd.yolov3 import Yolov3
+    m = Yolov3(device, out_channels=255)
+    m.init_synthetic(3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand((B, S, S, 3), generator=g).cuda(device)
+    tg = []
+    for d in (32, 16, 8):
+        t = torch.rand((B, S // d, S // d, 255), generator=g)
+        t4 = t.view(B, S // d, S // d, 3, 85)
+        t4[..., 4] = (t4[..., 4] > 0.9).float(); t4[..., 5:] = (t4[..., 5:] > 0.98).float()
+        tg.append(t.cuda(device))
+    for _ in range(2):
+        loss = m.train_on_batch(x, tg, HPS['lr'], HPS['beta_1'], HPS['beta_2'], HPS['decay'])
+    torch.cuda.synchronize(device)
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        loss = m.train_on_batch(x, tg, HPS['lr'], HPS['beta_1'], HPS['beta_2'], HPS['decay'])
+    e1.record(); torch.cuda.synchronize(device)
+    ms = e0.elapsed_time(e1) / steps
+    tf = m.train_flops_per_image(S) * B / (ms * 1e-3) / 1e12
+    out = dict(value=round(B / (ms * 1e-3), 1), unit='images/sec', ms_per_step=round(ms, 2), batch=B, image_size=S, steps=steps,
+               step_tflops=round(tf, 1), frac_of_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 4), loss=float(loss.item()),
+               workload='fv_yolov3_train_step + Adam: make_yolov3_model graph (yd.py:217-311), 255 output channels, synthetic targets')
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def pmc_traffic(B, S):
     """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes --
     only if the kernel sources are still the ones that were profiled (fingerprint recorded with the pass)."""
@@ -347,6 +383,9 @@ def main():
         loader = None
         if world == 1 and not args.no_loader:
             loader = loader_bench(eng, trainer, B, S, args.loader_steps)
+        three = None
+        if world == 1 and not args.no_three_scale and not args.no_detect:
+            three = three_scale_bench(local_rank, S)
         dom_name, dom = dominant(prof)
         roofline = None
         traffic, traffic_source = pmc_traffic(B, S)
@@ -387,6 +426,7 @@ def main():
                              if k in ('bn_act_stats_kernel', 'bn_bwd_apply_slots_kernel', 'bn_bwd_reduce_kernel', 'adam_kernel') and v['gbps']},
             'detect': detect,
             'loader_inclusive': loader,
+            'three_scale_train': three,
             'multi_gpu': multi,
             'kernels': kernels,
         }

@@ -43,6 +43,28 @@ class Yolov3(object):
         self.params.copy_(torch.as_tensor(params, dtype=torch.float32).reshape(-1))
         self.state.copy_(torch.as_tensor(state, dtype=torch.float32).reshape(-1))
 
+    def init_synthetic(self, seed=7):
+        """Random-init weights (no pretrained file offline): BN layers ~ N(0, 2/fan_in), gamma 1, beta 0, moving mean 0 /
+        var 1; the three detection convs glorot-uniform with zero bias (as Engine.init_synthetic)."""
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        p = torch.zeros(self.n_params, dtype=torch.float32); s = torch.zeros(self.n_state, dtype=torch.float32)
+        for d in self.layers:
+            k, cin, cout = d['ksize'], d['cin'], d['cout']
+            n = cout * k * k * cin
+            if d['has_bn']:
+                p[d['w_off']:d['w_off'] + n] = torch.randn(n, generator=g) * float(np.sqrt(2.0 / (k * k * cin)))
+                p[d['gamma_off']:d['gamma_off'] + cout] = 1.0
+                s[d['var_off']:d['var_off'] + cout] = 1.0
+            else:
+                lim = float(np.sqrt(6.0 / (k * k * cin + k * k * cout)))
+                p[d['w_off']:d['w_off'] + n] = (torch.rand(n, generator=g) * 2 - 1) * lim
+        self.set_params(p, s)
+
+    def train_flops_per_image(self, S):
+        """forward + weight-gradient of every conv + data-gradient of every conv but the first (2 FLOPs per MAC)."""
+        f = [2.0 * d['ksize'] ** 2 * d['cin'] * d['cout'] * (S // d['out_div']) ** 2 for d in self.layers]
+        return 3.0 * sum(f) - f[0]
+
     def load_darknet(self, path_or_bytes):
         """Full Darknet yolov3.weights (conv index order 0..105; yd.py:90-121)."""
         from .weights import header_len
