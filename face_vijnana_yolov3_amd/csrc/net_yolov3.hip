@@ -125,7 +125,7 @@ struct YTrain {
     std::vector<float*> z, a, mean, invstd, scale, shift, wt;
     std::vector<double*> slots, bslots;
     size_t slots_bytes = 0;
-    float *w0p, *cat61, *cat36, *y[3], *dy[3], *GA, *GB, *DZ, *gs61, *gs36, *r79, *r91, *loss_part, *colsum_part, *tail;
+    float *w0p, *cat61, *cat36, *y[3], *dy[3], *GA, *GB, *DZ, *DZ2, *gs61, *gs36, *r79, *r91, *loss_part, *colsum_part, *tail;
     size_t tail_floats = 0, bytes = 0;
     int cpad = 0;
 };
@@ -169,7 +169,7 @@ YTrain ytrain_plan(void* base, const YNet& N, int B, int S, int out_ch) {
         const size_t rows = (size_t)B * (S / (32 >> s)) * (S / (32 >> s));
         p.y[s] = c.take(rows * out_ch); p.dy[s] = c.take(rows * p.cpad);
     }
-    p.GA = c.take(max_act); p.GB = c.take(max_act); p.DZ = c.take(max_act);
+    p.GA = c.take(max_act); p.GB = c.take(max_act); p.DZ = c.take(max_act); p.DZ2 = c.take(max_act);
     p.gs61 = c.take((size_t)B * (S / 16) * (S / 16) * 512); p.gs36 = c.take((size_t)B * (S / 8) * (S / 8) * 256);
     p.r79 = c.take((size_t)B * (S / 32) * (S / 32) * 512); p.r91 = c.take((size_t)B * (S / 16) * (S / 16) * 256);
     p.loss_part = c.take(2 * 3 * 1024 + 64);
@@ -430,11 +430,37 @@ int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, cons
         bnr = FvBnRed{p.z[l], p.scale[l], p.shift[l], p.mean[l], p.invstd[l], p.bslots[l], fv_ew_bn_stat_slots(N.L[l].d.cout), LEAKY};
         return &bnr;
     };
+    // Weight-gradients run on the low-priority side stream, as in fv_train_step (net.hip): wgrad(l) needs only dz(l) and a saved
+    // forward activation, so the main stream goes on with dgrad(l) and the next layer's BN-backward.  dz alternates between two
+    // buffers; a buffer is rewritten only after the weight-gradient that read it has signalled ev_wg[slot].
+    const bool ov = ctx->overlap && ctx->side;
+    hipStream_t main_stream = ctx->stream;
+    float* const DZs[2] = {p.DZ, p.DZ2};
+    bool pend[2] = {false, false};
+    int slot = 0;
+    auto join = [&](int s) -> int {
+        if (pend[s]) { FV_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_wg[s], 0)); pend[s] = false; }
+        return FV_OK;
+    };
+    auto wgrad = [&](int s, const float* xin, const float* dyv, int H, int cin, int cout, int ndy, int ksize, int stride, float* dw) -> int {
+        if (!ov) return fv_op_conv_wgrad(ctx, xin, dyv, B, H, H, cin, cout, ndy, ksize, stride, dw);
+        FV_HIP(ctx, hipEventRecord(ctx->ev_dz[s], main_stream));
+        FV_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_dz[s], 0));
+        ctx->stream = ctx->side;
+        const int rc = fv_op_conv_wgrad(ctx, xin, dyv, B, H, H, cin, cout, ndy, ksize, stride, dw);
+        ctx->stream = main_stream;
+        if (rc) return rc;
+        FV_HIP(ctx, hipEventRecord(ctx->ev_wg[s], ctx->side));
+        pend[s] = true;
+        return FV_OK;
+    };
     // detection conv: dy (padded) -> dW, and g of its input layer `lin` (with that layer's d-beta/d-gamma reduction)
     auto det_bwd = [&](int l, int sidx, int lin, float* g_out) -> int {
         const auto& d = N.L[l].d;
         const int H = S / d.in_div;
-        if (int rc = fv_op_conv_wgrad(ctx, p.a[lin], p.dy[sidx], B, H, H, d.cin, d.cout, p.cpad, d.ksize, 1, grads + d.w_off)) return rc;
+        if (int rc = join(slot)) return rc;
+        if (int rc = wgrad(slot, p.a[lin], p.dy[sidx], H, d.cin, d.cout, p.cpad, d.ksize, 1, grads + d.w_off)) return rc;
+        slot ^= 1;
         return fv_op_conv_dgrad(ctx, p.dy[sidx], p.wt[l], B, H, H, d.cin, p.cpad, d.ksize, 1, nullptr, g_out, bnred(lin));
     };
     // BN layer l: g (its d-beta/d-gamma already in the slots unless !reduced) -> dz -> dW; data-gradient into g_out (+ addend),
@@ -443,11 +469,14 @@ int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, cons
         const auto& d = N.L[l].d;
         const int H = S / d.in_div, Ho = S / d.out_div;
         const long long rows = (long long)B * Ho * Ho;
+        if (int rc = join(slot)) return rc;
+        float* dz = DZs[slot];
         if (int rc = fv_ew_bn_bwd(ctx, g, p.z[l], p.scale[l], p.shift[l], p.mean[l], p.invstd[l], rows, d.cout, LEAKY, nullptr, nullptr,
-                                  grads + d.beta_off, grads + d.gamma_off, p.DZ, p.bslots[l], fv_ew_bn_stat_slots(d.cout), reduced)) return rc;
-        if (int rc = fv_op_conv_wgrad(ctx, xin, p.DZ, B, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off)) return rc;
+                                  grads + d.beta_off, grads + d.gamma_off, dz, p.bslots[l], fv_ew_bn_stat_slots(d.cout), reduced)) return rc;
+        if (int rc = wgrad(slot, xin, dz, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off)) return rc;
+        slot ^= 1;
         if (!g_out) return FV_OK;
-        return fv_op_conv_dgrad(ctx, p.DZ, p.wt[l], B, H, H, d.cin, d.cout, d.ksize, d.stride, addend, g_out, bnred(lred));
+        return fv_op_conv_dgrad(ctx, dz, p.wt[l], B, H, H, d.cin, d.cout, d.ksize, d.stride, addend, g_out, bnred(lred));
     };
     float *ga = p.GA, *gb = p.GB;
     auto swap = [&]() { float* t = ga; ga = gb; gb = t; };
@@ -490,7 +519,8 @@ int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, cons
             if (d.role == 1) ires = -1;
         }
     }
-    return FV_OK;
+    if (int rc = join(0)) return rc;
+    return join(1);
 }
 
 }  // extern "C"
