@@ -72,6 +72,12 @@ int fv_set_conv_waves8(fv_ctx* ctx, int on) {
     return FV_OK;
 }
 
+int fv_set_bn_zero_debias_step(fv_ctx* ctx, long long step) {
+    if (!ctx || step < 0) return FV_ERR_INVALID;
+    ctx->bn_ema_step = step;
+    return FV_OK;
+}
+
 int fv_set_conv0_direct(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;
     ctx->conv0_direct = on != 0;

@@ -14,7 +14,7 @@ namespace {
 // partial sums [mtiles][C] (from the conv epilogue) -> mean, invstd, scale, shift, moving stats.
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
                                                            int mtiles, int C, double count, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float eps, float momentum,
+                                                           const float* __restrict__ beta, float eps, float ema_old, float ema_new,
                                                            float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                                            float* __restrict__ scale_out, float* __restrict__ shift_out,
                                                            float* __restrict__ moving_mean, float* __restrict__ moving_var) {
@@ -46,8 +46,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         if (moving_mean) {
             // Keras 2.2.4 BatchNormalization: EMA of batch mean and of var * n/(n-(1+eps))
             double corr = count / (count - (1.0 + (double)eps));
-            moving_mean[c] = momentum * moving_mean[c] + (1.0f - momentum) * (float)mean;
-            moving_var[c] = momentum * moving_var[c] + (1.0f - momentum) * (float)(var * corr);
+            moving_mean[c] = ema_old * moving_mean[c] + ema_new * (float)mean;
+            moving_var[c] = ema_old * moving_var[c] + ema_new * (float)(var * corr);
         }
     }
 }
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float4* __restrict__ 
 // for the backward pass and updates the moving statistics -- no finalize launch in between.
 __global__ __launch_bounds__(256) void bn_act_stats_kernel(const float4* __restrict__ z, const double* __restrict__ slots, int nslot,
                                                            double count, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float eps, float momentum, float* __restrict__ mean_out,
+                                                           float eps, float ema_old, float ema_new, float* __restrict__ mean_out,
                                                            float* __restrict__ invstd_out, float* __restrict__ scale_out,
                                                            float* __restrict__ shift_out, float* __restrict__ moving_mean,
                                                            float* __restrict__ moving_var, const float4* __restrict__ skip,
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void bn_act_stats_kernel(const float4* __restr
             mean_out[c] = (float)mean; invstd_out[c] = invstd; scale_out[c] = sc; shift_out[c] = sh;
             if (moving_mean) {   // Keras 2.2.4 BatchNormalization: EMA of batch mean and of var * n/(n-(1+eps))
                 const double corr = count / (count - (1.0 + (double)eps));
-                moving_mean[c] = momentum * moving_mean[c] + (1.0f - momentum) * (float)mean;
-                moving_var[c] = momentum * moving_var[c] + (1.0f - momentum) * (float)(var * corr);
+                moving_mean[c] = ema_old * moving_mean[c] + ema_new * (float)mean;
+                moving_var[c] = ema_old * moving_var[c] + ema_new * (float)(var * corr);
             }
         }
     };
@@ -615,12 +615,27 @@ inline int grid_for(long long n, int block, int cap = 256 * 8) {
 
 }  // namespace
 
+// Coefficients of moving <- ema_old * moving + ema_new * batch.  Plain EMA: (momentum, 1 - momentum).  With
+// fv_set_bn_zero_debias_step(t >= 1): the update Keras 2.2.4 performs through TF 1.x
+// moving_averages.assign_moving_average(..., zero_debias=True) (reference yd.py:212 BatchNormalization): a zero-initialised biased
+// accumulator b_t = m b_{t-1} + (1 - m) x_t and moving_t = b_t / (1 - m^t); with b_{t-1} = moving_{t-1} (1 - m^{t-1}) that is
+// ema_old = m (1 - m^{t-1}) / (1 - m^t), ema_new = (1 - m) / (1 - m^t) -- the first update replaces the stored value outright.
+static inline void bn_ema_coeff(const fv_ctx* ctx, float momentum, float* c_old, float* c_new) {
+    if (ctx->bn_ema_step <= 0) { *c_old = momentum; *c_new = 1.0f - momentum; return; }
+    const double m = (double)momentum, t = (double)ctx->bn_ema_step;
+    const double den = 1.0 - pow(m, t);
+    *c_old = (float)(m * (1.0 - pow(m, t - 1.0)) / den);
+    *c_new = (float)((1.0 - m) / den);
+}
+
 int fv_ew_bn_finalize(fv_ctx* ctx, const float* psum, const float* psq, int mtiles, int C, double count, const float* gamma,
                       const float* beta, float eps, float momentum, float* mean, float* invstd, float* scale, float* shift,
                       float* moving_mean, float* moving_var) {
     FvProfScope ps(ctx, "bn_finalize_kernel", 0.0, 8.0 * mtiles * C);
+    float ema_old, ema_new;
+    bn_ema_coeff(ctx, momentum, &ema_old, &ema_new);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, ctx->stream, psum, psq, mtiles, C, count, gamma,
-                       beta, eps, momentum, mean, invstd, scale, shift, moving_mean, moving_var);
+                       beta, eps, ema_old, ema_new, mean, invstd, scale, shift, moving_mean, moving_var);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }
@@ -658,8 +673,10 @@ int fv_ew_bn_act_stats(fv_ctx* ctx, const float* z, const double* slots, int nsl
     FvProfScope ps(ctx, "bn_act_stats_kernel", 0.0, 4.0 * rows * C * (skip ? 3 : 2));
     // 4 workgroups per CU: the slot reduction in front of the stream is paid once per workgroup (measured:
     // 4096 / 2048 / 1024 / 512 workgroups -> 2.78 / 2.57 / 2.47 / 3.03 ms per step over the 52 layers)
+    float ema_old, ema_new;
+    bn_ema_coeff(ctx, momentum, &ema_old, &ema_new);
     hipLaunchKernelGGL(bn_act_stats_kernel, dim3(grid_for(n4, 256, 256 * 4)), dim3(256), 0, ctx->stream, (const float4*)z, slots, nslot,
-                       count, gamma, beta, eps, momentum, mean, invstd, scale, shift, moving_mean, moving_var, (const float4*)skip,
+                       count, gamma, beta, eps, ema_old, ema_new, mean, invstd, scale, shift, moving_mean, moving_var, (const float4*)skip,
                        (float4*)out, n4, C, leaky);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;

@@ -47,6 +47,10 @@ class Engine(object):
         self.m = None
         self.v = None
         self.iterations = 0
+        # Keras 2.2.4 / TF 1.x update of the BN moving statistics (zero-debiased, fv_set_bn_zero_debias_step) instead of the plain
+        # EMA; bn_updates counts the training steps of THIS object (TF keeps the step in a graph variable that load_model rebuilds)
+        self.bn_zero_debias = False
+        self.bn_updates = 0
         self._ws = {}
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self._bucket_cb = None
@@ -137,11 +141,13 @@ class Engine(object):
         else:
             cb = ctypes.cast(None, BUCKET_FN)
         self._bucket_cb = cb  # keep alive during the call
+        self.ctx.set_bn_zero_debias_step(self.bn_updates + 1 if self.bn_zero_debias else 0)
         rc = lib().fv_train_step(self.ctx.handle, ptr(self.params), ptr(self.state), ptr(x), ptr(y_true), B, S, ptr(ws),
                                  ws.numel(), ptr(self.grads), ptr(self._loss), cb, None)
         self.ctx.check(rc, 'fv_train_step')
         if cb_error:
             raise cb_error[0]
+        self.bn_updates += 1
         return self._loss
 
     def train_tensor(self, batch, image_size, layer, which):

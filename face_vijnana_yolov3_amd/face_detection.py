@@ -58,6 +58,9 @@ class FaceDetector(object):
         if device is None:
             device = int(os.environ.get('LOCAL_RANK', 0))
         self.model = Engine(device)
+        # BN moving statistics as the reference's stack updates them (Keras 2.2.4: zero-debiased); "bn_zero_debias": false in the
+        # configuration selects the plain EMA
+        self.model.bn_zero_debias = bool(conf.get('bn_zero_debias', True))
         if self.model_loading:
             self.model.load(self.MODEL_PATH)
         else:

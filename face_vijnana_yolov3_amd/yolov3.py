@@ -38,6 +38,8 @@ class Yolov3(object):
         self.grads = self.m = self.v = None
         self.iterations = 0
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self.bn_zero_debias = False      # Engine.bn_zero_debias: Keras 2.2.4's zero-debiased moving statistics
+        self.bn_updates = 0
 
     def set_params(self, params, state):
         self.params.copy_(torch.as_tensor(params, dtype=torch.float32).reshape(-1))
@@ -118,9 +120,11 @@ class Yolov3(object):
         for y, dv in zip(t, (32, 16, 8)):
             assert y.numel() == B * (S // dv) ** 2 * self.out_channels, tuple(y.shape)
         ws = self._train_ws(B, S)
+        self.ctx.set_bn_zero_debias_step(self.bn_updates + 1 if self.bn_zero_debias else 0)
         rc = lib().fv_yolov3_train_step(self.ctx.handle, ptr(self.params), ptr(self.state), ptr(x), ptr(t[0]), ptr(t[1]), ptr(t[2]), B, S,
                                         self.out_channels, ptr(ws), ws.numel(), ptr(self.grads), ptr(self._loss))
         self.ctx.check(rc, 'fv_yolov3_train_step')
+        self.bn_updates += 1
         return self._loss
 
     def adam_step(self, lr, beta_1, beta_2, decay=0.0, eps=1e-7):

@@ -61,6 +61,14 @@ int fv_set_tail_split(fv_ctx* ctx, int on);
  * workgroups, 8 waves of 64x32 -- four waves per SIMD cover each other's barriers and LDS latency; 0: 256 threads,
  * 4 waves of 64x64.  Same k-ordered fmaf chain per output element: bit-identical results. */
 int fv_set_conv_waves8(fv_ctx* ctx, int on);
+/* Update rule of the BatchNormalization moving mean / variance in every training-mode BN launch that follows (reference
+ * yd.py:212 `BatchNormalization(epsilon=0.001)`; the update itself is third-party: Keras 2.2.4 `K.moving_average_update` ->
+ * TF 1.x `assign_moving_average(..., zero_debias=True)`).  step = 0 (default): plain EMA, moving <- m moving + (1 - m) batch.
+ * step = t >= 1: the t-th zero-debiased update since the model was built, moving_t = b_t / (1 - m^t) with the zero-initialised
+ * b_t = m b_{t-1} + (1 - m) batch_t -- the first update REPLACES the stored value (so loaded Darknet statistics are forgotten
+ * at the first training step, as in the reference's stack).  The caller advances t once per training step.  Parity unpinned
+ * (neither Keras nor TF is importable here). */
+int fv_set_bn_zero_debias_step(fv_ctx* ctx, long long step);
 /* First layer (3 -> 32 channels, K = 27, HBM-bound): 1 (default) a direct vector-FMA kernel with an LDS halo tile
  * whenever W % 32 == 0 and H % 8 == 0; 0 the matrix-core gather kernel.  Bit-identical outputs (same fmaf chain). */
 int fv_set_conv0_direct(fv_ctx* ctx, int on);

@@ -98,7 +98,18 @@ def _conv(x_nchw, w_ohwi, k, s):
     return F.conv2d(x_nchw, w, stride=s)
 
 
-def forward(params, state, x_nhwc, training, update_state=True, return_intermediates=False, positive=None):
+def ema_coefficients(step=0, momentum=None):
+    """(c_old, c_new) of moving <- c_old*moving + c_new*batch.  step 0: plain EMA.  step t >= 1: the t-th update of TF 1.x
+    `assign_moving_average(..., zero_debias=True)` as Keras 2.2.4's K.moving_average_update calls it: zero-initialised
+    biased accumulator b_t = m b_{t-1} + (1-m) x_t, moving_t = b_t / (1 - m^t), written in terms of moving_{t-1}."""
+    m = BN_MOMENTUM if momentum is None else momentum
+    if step <= 0:
+        return m, 1 - m
+    den = 1.0 - m ** step
+    return m * (1.0 - m ** (step - 1)) / den, (1.0 - m) / den
+
+
+def forward(params, state, x_nhwc, training, update_state=True, return_intermediates=False, positive=None, ema_step=0):
     """x (B,S,S,3) -> (B,S/32,S/32,6).  training=True uses batch statistics and returns the new
     moving state as second value; training=False uses `state` (Keras predict).
 
@@ -133,8 +144,9 @@ def forward(params, state, x_nhwc, training, update_state=True, return_intermedi
                 with torch.no_grad():
                     mm = state[e['mean_off']:e['mean_off'] + cout]
                     mv = state[e['var_off']:e['var_off'] + cout]
-                    new_state[e['mean_off']:e['mean_off'] + cout] = BN_MOMENTUM * mm + (1 - BN_MOMENTUM) * mean
-                    new_state[e['var_off']:e['var_off'] + cout] = BN_MOMENTUM * mv + (1 - BN_MOMENTUM) * var * (n / (n - (1.0 + BN_EPS)))
+                    c_old, c_new = ema_coefficients(ema_step)
+                    new_state[e['mean_off']:e['mean_off'] + cout] = c_old * mm + c_new * mean
+                    new_state[e['var_off']:e['var_off'] + cout] = c_old * mv + c_new * var * (n / (n - (1.0 + BN_EPS)))
         else:
             mean = state[e['mean_off']:e['mean_off'] + cout]
             var = state[e['var_off']:e['var_off'] + cout]

@@ -195,6 +195,42 @@ def test_train_step_416_batch2_is_tight_on_the_device_branch(eng):
     _tight_step_check(eng, 23, 2, 416, rep)
 
 
+def test_bn_zero_debias_moving_statistics(eng):
+    """fv_set_bn_zero_debias_step / Engine.bn_zero_debias: the Keras 2.2.4 (TF 1.x assign_moving_average, zero_debias=True)
+    update of the BN moving statistics, two consecutive training steps.  Expected values from an EXPLICIT zero-initialised
+    biased accumulator b_t = m b_{t-1} + (1 - m) x_t, moving_t = b_t / (1 - m^t) (the device and oracle.ema_coefficients use
+    the form rewritten in terms of moving_{t-1}); x_t = the oracle's batch statistics of step t (its update with c_old = 0,
+    c_new = 1).  Step 1 must REPLACE whatever was stored.  Parity unpinned against Keras itself (not importable)."""
+    from oracle import net_oracle as no
+    B, S = 3, 64
+    p64, s64, x, yt = _setup(31, B, S)
+    s64 = s64 + 0.37                                   # a stored value that the first update has to forget
+    m = no.BN_MOMENTUM
+    eng.set_params(p64.float(), s64.float())
+    eng.iterations = 0; eng.m = eng.v = eng.grads = None
+    eng.bn_zero_debias, eng.bn_updates = True, 0
+    try:
+        eng.train_on_batch(x.float(), yt.float(), 1e-4, 0.9, 0.999)
+        torch.cuda.synchronize()
+        st1 = eng.state.cpu().double(); p1 = eng.params.cpu().double()
+        eng.train_on_batch(x.float(), yt.float(), 1e-4, 0.9, 0.999)
+        torch.cuda.synchronize()
+        st2 = eng.state.cpu().double()
+    finally:
+        eng.bn_zero_debias, eng.bn_updates = False, 0
+        eng.ctx.set_bn_zero_debias_step(0)
+    _, x1 = no.forward(p64, s64, x, training=True, ema_step=1)          # c_old = 0: the batch statistics themselves
+    _, x2 = no.forward(p1, s64, x, training=True, ema_step=1)
+    b1 = (1 - m) * x1
+    b2 = m * b1 + (1 - m) * x2
+    want1, want2 = b1 / (1 - m), b2 / (1 - m * m)
+    assert (st1 - want1).abs().max().item() <= 2e-5 * max(1.0, want1.abs().max().item())
+    assert (st2 - want2).abs().max().item() <= 2e-5 * max(1.0, want2.abs().max().item())
+    # and the plain EMA (default) keeps 99 % of the stored value: the two rules are far apart after one step
+    _, ema = no.forward(p64, s64, x, training=True)
+    assert (ema - want1).abs().max().item() > 0.1
+
+
 def test_workspace_too_small_is_reported(eng):
     import ctypes
     from face_vijnana_yolov3_amd._lib import lib, ptr

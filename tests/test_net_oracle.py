@@ -163,3 +163,21 @@ def test_three_scale_training_forward_consistency():
             pass
     # (moving statistics after ONE update from zero momentum would equal batch statistics; here just shape/finite checks)
     assert all(o.shape == t.shape for o, t in zip(outs_t, tg))
+
+
+def test_zero_debias_coefficients_equal_the_explicit_accumulator():
+    """oracle.ema_coefficients(t): moving_t = c_old moving_{t-1} + c_new x_t reproduces TF 1.x zero_debias (biased accumulator
+    from zero, divided by 1 - m^t) for every t, whatever the stored value before the first update."""
+    import numpy as np
+    from oracle import net_oracle as no
+    rng = np.random.default_rng(3)
+    m = no.BN_MOMENTUM
+    xs = rng.normal(size=(12, 5))
+    moving = rng.normal(size=5) + 4.0
+    b = np.zeros(5)
+    for t, xt in enumerate(xs, 1):
+        b = m * b + (1 - m) * xt
+        c_old, c_new = no.ema_coefficients(t)
+        moving = c_old * moving + c_new * xt
+        assert np.allclose(moving, b / (1 - m ** t), rtol=1e-12, atol=1e-12)
+    assert no.ema_coefficients(0) == (m, 1 - m)
