@@ -124,6 +124,12 @@ WGRAD_CASES = [
     (1, 26, 256, 128, 1, 1, 128),
     (4, 26, 128, 256, 3, 1, 256),
     (2, 16, 256, 512, 3, 1, 512),   # >= 64 (tile, tap) workgroups per K-split: plain split order
+    # lattices smaller than one 32-pixel chunk: the row table's image / row / column carries all fire within a chunk
+    (5, 3, 128, 128, 3, 1, 128),    # 3x3 lattice: a chunk spans 3.6 images
+    (7, 4, 128, 256, 3, 2, 256),    # stride 2 -> 2x2 lattice: 8 images per chunk
+    (3, 5, 64, 64, 3, 1, 64),       # split form, 25-pixel images
+    (9, 2, 256, 128, 1, 1, 128),    # 1x1 on a 2x2 lattice
+    (2, 33, 32, 64, 3, 1, 64),      # row length 33: the column wraps at a different lane every chunk
 ]
 
 
