@@ -68,6 +68,7 @@ def _declare(L):
         'fv_set_fused_bn_backward': (i32, [vp, i32]),
         'fv_set_conv0_direct': (i32, [vp, i32]),
         'fv_set_conv_waves8': (i32, [vp, i32]),
+        'fv_set_wgrad_fused_taps': (i32, [vp, i32]),
         'fv_set_bn_zero_debias_step': (i32, [vp, ctypes.c_longlong]),
         'fv_profile_enable': (i32, [vp, i32]),
         'fv_profile_collect': (i32, [vp, ctypes.POINTER(ProfileRec), i32, ctypes.POINTER(i32)]),
@@ -160,6 +161,9 @@ class Context:
 
     def set_bn_zero_debias_step(self, step):
         self.check(lib().fv_set_bn_zero_debias_step(self._h, int(step)), 'fv_set_bn_zero_debias_step')
+
+    def set_wgrad_fused_taps(self, on):
+        self.check(lib().fv_set_wgrad_fused_taps(self._h, 1 if on else 0), 'fv_set_wgrad_fused_taps')
 
     def set_conv_waves8(self, on):
         self.check(lib().fv_set_conv_waves8(self._h, 1 if on else 0), 'fv_set_conv_waves8')

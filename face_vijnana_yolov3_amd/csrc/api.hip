@@ -78,6 +78,12 @@ int fv_set_bn_zero_debias_step(fv_ctx* ctx, long long step) {
     return FV_OK;
 }
 
+int fv_set_wgrad_fused_taps(fv_ctx* ctx, int on) {
+    if (!ctx) return FV_ERR_INVALID;
+    ctx->wgrad_fused_taps = on != 0;
+    return FV_OK;
+}
+
 int fv_set_conv0_direct(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;
     ctx->conv0_direct = on != 0;

@@ -61,6 +61,10 @@ int fv_set_tail_split(fv_ctx* ctx, int on);
  * workgroups, 8 waves of 64x32 -- four waves per SIMD cover each other's barriers and LDS latency; 0: 256 threads,
  * 4 waves of 64x64.  Same k-ordered fmaf chain per output element: bit-identical results. */
 int fv_set_conv_waves8(fv_ctx* ctx, int on);
+/* Weight-gradient of the 3x3 layers with 32 input and 64 output channels (conv_1, conv_3): 1 (default) one workgroup stages
+ * the x halo and the dy tile of a 4x16-pixel unit once and multiplies all nine taps from it (wgrad9_mfma.hip); 0 the generic
+ * kernel, one workgroup per tap.  Same products, different float-atomic summation order. */
+int fv_set_wgrad_fused_taps(fv_ctx* ctx, int on);
 /* Update rule of the BatchNormalization moving mean / variance in every training-mode BN launch that follows (reference
  * yd.py:212 `BatchNormalization(epsilon=0.001)`; the update itself is third-party: Keras 2.2.4 `K.moving_average_update` ->
  * TF 1.x `assign_moving_average(..., zero_debias=True)`).  step = 0 (default): plain EMA, moving <- m moving + (1 - m) batch.

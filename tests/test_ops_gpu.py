@@ -130,7 +130,29 @@ WGRAD_CASES = [
     (3, 5, 64, 64, 3, 1, 64),       # split form, 25-pixel images
     (9, 2, 256, 128, 1, 1, 128),    # 1x1 on a 2x2 lattice
     (2, 33, 32, 64, 3, 1, 64),      # row length 33: the column wraps at a different lane every chunk
+    # the fused nine-tap kernel (32 -> 64 channels): whole units, ragged units in both directions, both strides, padded dy
+    (2, 16, 32, 64, 3, 1, 64),
+    (3, 13, 32, 64, 3, 1, 64),
+    (2, 20, 32, 64, 3, 2, 64),
+    (1, 38, 32, 64, 3, 2, 128),
+    (5, 4, 32, 64, 3, 1, 64),
 ]
+
+
+def test_wgrad_fused_taps_equals_generic(ctx):
+    """fv_set_wgrad_fused_taps: the nine-tap kernel and the one-workgroup-per-tap kernel form the same products; only the
+    order of the float additions differs."""
+    from face_vijnana_yolov3_amd import ops
+    for (B, H, s) in [(3, 40, 1), (2, 52, 2)]:
+        x = _rand((B, H, H, 32), 81).cuda(); dy = _rand((B, H // s, H // s, 64), 82).cuda()
+        got = ops.conv2d_wgrad(ctx, x, dy, 64, 3, s)
+        ctx.set_wgrad_fused_taps(False)
+        try:
+            ref = ops.conv2d_wgrad(ctx, x, dy, 64, 3, s)
+        finally:
+            ctx.set_wgrad_fused_taps(True)
+        scale = ref.abs().max().item()
+        assert (got - ref).abs().max().item() <= 2e-5 * scale, (B, H, s)
 
 
 @pytest.mark.parametrize('B,H,cin,cout,k,s,ndy', WGRAD_CASES)
