@@ -84,6 +84,12 @@ int fv_set_wgrad_fused_taps(fv_ctx* ctx, int on) {
     return FV_OK;
 }
 
+int fv_set_conv_halo_forward(fv_ctx* ctx, int on) {
+    if (!ctx) return FV_ERR_INVALID;
+    ctx->conv_halo_fwd = on != 0;
+    return FV_OK;
+}
+
 int fv_set_conv0_direct(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;
     ctx->conv0_direct = on != 0;

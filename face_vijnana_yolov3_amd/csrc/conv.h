@@ -96,6 +96,9 @@ int fv_conv_choose_ksplit(int M, int Nout, int ksteps);
 // number of whole tiles, and the floats of slab scratch it needs.
 void fv_conv_tail_plan(int M, int Nout, int ksteps, int* tail_f, int* tail_full, long long* slab_floats);
 int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a);
+// conv9_mfma.hip: training forward of the 32 -> 64 channel 3x3 layers from an LDS halo tile with resident weights (bit-identical z)
+bool fv_conv9_fwd_ok(const FvConvArgs& a);
+int fv_conv9_fwd_launch(fv_ctx* ctx, const FvConvArgs& a);
 // conv0_direct.hip: the 3 -> 32 channel first layer as a direct vector-FMA convolution (bit-identical to the gather kernel)
 bool fv_conv0_direct_ok(const FvConvArgs& a);
 int fv_conv0_direct_launch(fv_ctx* ctx, const FvConvArgs& a);

@@ -65,6 +65,11 @@ int fv_set_conv_waves8(fv_ctx* ctx, int on);
  * the x halo and the dy tile of a 4x16-pixel unit once and multiplies all nine taps from it (wgrad9_mfma.hip); 0 the generic
  * kernel, one workgroup per tap.  Same products, different float-atomic summation order. */
 int fv_set_wgrad_fused_taps(fv_ctx* ctx, int on);
+/* Training-mode forward (raw z + statistics slots) of the 3x3 layers with 32 input and 64 output channels (conv_1, conv_3):
+ * 1 (default) one workgroup per CU keeps all weights in LDS and multiplies units of 8x16 output pixels from an x halo tile
+ * staged once (conv9_mfma.hip); 0 the generic tile kernel.  Same k-ordered fmaf chain: z is bit-identical; the statistics
+ * are the same sums accumulated in another order (fp64). */
+int fv_set_conv_halo_forward(fv_ctx* ctx, int on);
 /* Update rule of the BatchNormalization moving mean / variance in every training-mode BN launch that follows (reference
  * yd.py:212 `BatchNormalization(epsilon=0.001)`; the update itself is third-party: Keras 2.2.4 `K.moving_average_update` ->
  * TF 1.x `assign_moving_average(..., zero_debias=True)`).  step = 0 (default): plain EMA, moving <- m moving + (1 - m) batch.

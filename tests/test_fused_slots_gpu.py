@@ -378,3 +378,26 @@ def test_eight_wave_conv_equals_four_wave_conv(ctx, B, H, cin, cout, k, s):
         assert torch.equal(res[True][i], res[False][i]), i
     mag = res[False][5].abs().max().item()
     torch.testing.assert_close(res[True][5], res[False][5], rtol=2e-5, atol=2e-5 * mag)
+
+
+@pytest.mark.parametrize('B,H,s', [(2, 16, 1), (3, 13, 1), (2, 20, 2), (1, 38, 2), (5, 4, 1), (2, 48, 2), (41, 16, 1)])
+def test_halo_forward_is_bit_identical_to_the_tile_kernel(ctx, B, H, s):
+    """fv_set_conv_halo_forward (conv9_mfma.hip: 32 -> 64 channels, 3x3, training forward): resident weights + one x halo
+    tile per 8x16-pixel unit, same k-ordered fmaf chain as conv_kernel<64,...> -> z bit-identical (whole, ragged and tiny
+    units, both strides, more units than workgroups); the statistics slots hold the same column sums in another order."""
+    from face_vijnana_yolov3_amd import ops
+    x = _rand((B, H, H, 32), 91).cuda(); w = _rand((64, 3, 3, 32), 92, -0.2, 0.2).cuda()
+    sl = ops.stat_slots(64, 'cuda')
+    z = ops.conv2d_forward_slots(ctx, x, w, s, sl)
+    ctx.set_conv_halo_forward(False)
+    try:
+        sl0 = ops.stat_slots(64, 'cuda')
+        z0 = ops.conv2d_forward_slots(ctx, x, w, s, sl0)
+    finally:
+        ctx.set_conv_halo_forward(True)
+    assert torch.equal(z, z0)
+    zc = z.double().view(-1, 64)
+    s1, s0 = sl.sum(0).cpu(), sl0.sum(0).cpu()
+    assert ((s1[0] - zc.sum(0).cpu()).abs() <= 1e-6 * zc.abs().sum(0).cpu() + 1e-9).all()
+    assert ((s1[1] - (zc * zc).sum(0).cpu()).abs() <= 1e-6 * (zc * zc).sum(0).cpu() + 1e-9).all()
+    assert ((s1 - s0).abs() <= 2e-5 * s0.abs() + 1e-5).all()
