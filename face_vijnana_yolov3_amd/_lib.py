@@ -68,7 +68,7 @@ def _declare(L):
         'fv_set_fused_bn_backward': (i32, [vp, i32]),
         'fv_set_conv0_direct': (i32, [vp, i32]),
         'fv_set_conv_waves8': (i32, [vp, i32]),
-        'fv_set_conv_halo_forward': (i32, [vp, i32]),
+        'fv_set_conv_halo': (i32, [vp, i32]),
         'fv_set_wgrad_fused_taps': (i32, [vp, i32]),
         'fv_set_bn_zero_debias_step': (i32, [vp, ctypes.c_longlong]),
         'fv_profile_enable': (i32, [vp, i32]),
@@ -166,8 +166,8 @@ class Context:
     def set_wgrad_fused_taps(self, on):
         self.check(lib().fv_set_wgrad_fused_taps(self._h, 1 if on else 0), 'fv_set_wgrad_fused_taps')
 
-    def set_conv_halo_forward(self, on):
-        self.check(lib().fv_set_conv_halo_forward(self._h, 1 if on else 0), 'fv_set_conv_halo_forward')
+    def set_conv_halo(self, on):
+        self.check(lib().fv_set_conv_halo(self._h, 1 if on else 0), 'fv_set_conv_halo')
 
     def set_conv_waves8(self, on):
         self.check(lib().fv_set_conv_waves8(self._h, 1 if on else 0), 'fv_set_conv_waves8')

@@ -84,9 +84,9 @@ int fv_set_wgrad_fused_taps(fv_ctx* ctx, int on) {
     return FV_OK;
 }
 
-int fv_set_conv_halo_forward(fv_ctx* ctx, int on) {
+int fv_set_conv_halo(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;
-    ctx->conv_halo_fwd = on != 0;
+    ctx->conv_halo = on != 0;
     return FV_OK;
 }
 

@@ -34,7 +34,7 @@ struct fv_ctx {
     bool conv_waves8 = true;     // 512-thread (8-wave) form of the 128x128 conv kernel (FV_CONV_WAVES8=0: the 4-wave form)
     long long bn_ema_step = 0;   // fv_set_bn_zero_debias_step: 0 plain EMA of the BN moving statistics, t >= 1 Keras 2.2.4's zero-debiased update t
     bool wgrad_fused_taps = true;   // fv_set_wgrad_fused_taps: wgrad9_mfma.hip for the 32 -> 64 channel 3x3 layers
-    bool conv_halo_fwd = true;      // fv_set_conv_halo_forward: conv9_mfma.hip for the training forward of the 32 -> 64 channel 3x3 layers
+    bool conv_halo = true;      // fv_set_conv_halo: conv9_mfma.hip (training forward) and dgrad9s2_mfma.hip (stride-2 data-gradient) for the 32 -> 64 channel 3x3 layers
     bool conv0_direct = true;    // fv_set_conv0_direct: vector-FMA first layer (conv0_direct.hip) instead of the gather kernel
     bool fused_bn_bwd = false;   // fv_set_fused_bn_backward: BN-backward apply folded into the consumers' operand loads
     ~fv_ctx();

@@ -986,7 +986,8 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
                                                  !(a.epi & (FV_EPI_STATS | FV_EPI_AFFINE | FV_EPI_LEAKY))),
                "conv: fused BN-backward reduction needs its layer's tensors, 16-byte rows and a plain (+add) epilogue");
     FV_REQUIRE(ctx, a.ksplit <= 1 || (a.epi == 0 && a.nclass == 1 && a.Cin % BK == 0), "conv: split-K stores raw partials only");
-    if (ctx->conv_halo_fwd && fv_conv9_fwd_ok(a)) return fv_conv9_fwd_launch(ctx, a);
+    if (ctx->conv_halo && fv_conv9_fwd_ok(a)) return fv_conv9_fwd_launch(ctx, a);
+    if (ctx->conv_halo && fv_dgrad9s2_ok(a)) return fv_dgrad9s2_launch(ctx, a);
     const bool gather = a.Cin % BK != 0;
     if (gather) {
         FV_REQUIRE(ctx, 9 * a.Cin <= BK && a.nclass == 1 && a.is == 1 && a.os == 1 && a.taps[0].n == 9 &&

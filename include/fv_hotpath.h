@@ -65,11 +65,12 @@ int fv_set_conv_waves8(fv_ctx* ctx, int on);
  * the x halo and the dy tile of a 4x16-pixel unit once and multiplies all nine taps from it (wgrad9_mfma.hip); 0 the generic
  * kernel, one workgroup per tap.  Same products, different float-atomic summation order. */
 int fv_set_wgrad_fused_taps(fv_ctx* ctx, int on);
-/* Training-mode forward (raw z + statistics slots) of the 3x3 layers with 32 input and 64 output channels (conv_1, conv_3):
- * 1 (default) one workgroup per CU keeps all weights in LDS and multiplies units of 8x16 output pixels from an x halo tile
- * staged once (conv9_mfma.hip); 0 the generic tile kernel.  Same k-ordered fmaf chain: z is bit-identical; the statistics
- * are the same sums accumulated in another order (fp64). */
-int fv_set_conv_halo_forward(fv_ctx* ctx, int on);
+/* Halo-tile kernels for the 3x3 layers with 32 input and 64 output channels (conv_1, conv_3): 1 (default) the training-mode
+ * forward (raw z + statistics slots; conv9_mfma.hip) and the stride-2 data-gradient with or without the fused BN-backward
+ * reduction (dgrad9s2_mfma.hip) run one workgroup per CU that keeps all weights in LDS and multiplies units of 8x16 pixels
+ * from an operand halo tile staged once; 0 the generic tile kernel.  Same k-ordered fmaf chains: z and dx are bit-identical;
+ * the statistics / reduction sums are the same sums accumulated in another order (fp64). */
+int fv_set_conv_halo(fv_ctx* ctx, int on);
 /* Update rule of the BatchNormalization moving mean / variance in every training-mode BN launch that follows (reference
  * yd.py:212 `BatchNormalization(epsilon=0.001)`; the update itself is third-party: Keras 2.2.4 `K.moving_average_update` ->
  * TF 1.x `assign_moving_average(..., zero_debias=True)`).  step = 0 (default): plain EMA, moving <- m moving + (1 - m) batch.

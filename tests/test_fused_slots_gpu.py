@@ -382,22 +382,61 @@ def test_eight_wave_conv_equals_four_wave_conv(ctx, B, H, cin, cout, k, s):
 
 @pytest.mark.parametrize('B,H,s', [(2, 16, 1), (3, 13, 1), (2, 20, 2), (1, 38, 2), (5, 4, 1), (2, 48, 2), (41, 16, 1)])
 def test_halo_forward_is_bit_identical_to_the_tile_kernel(ctx, B, H, s):
-    """fv_set_conv_halo_forward (conv9_mfma.hip: 32 -> 64 channels, 3x3, training forward): resident weights + one x halo
+    """fv_set_conv_halo (conv9_mfma.hip: 32 -> 64 channels, 3x3, training forward): resident weights + one x halo
     tile per 8x16-pixel unit, same k-ordered fmaf chain as conv_kernel<64,...> -> z bit-identical (whole, ragged and tiny
     units, both strides, more units than workgroups); the statistics slots hold the same column sums in another order."""
     from face_vijnana_yolov3_amd import ops
     x = _rand((B, H, H, 32), 91).cuda(); w = _rand((64, 3, 3, 32), 92, -0.2, 0.2).cuda()
     sl = ops.stat_slots(64, 'cuda')
     z = ops.conv2d_forward_slots(ctx, x, w, s, sl)
-    ctx.set_conv_halo_forward(False)
+    ctx.set_conv_halo(False)
     try:
         sl0 = ops.stat_slots(64, 'cuda')
         z0 = ops.conv2d_forward_slots(ctx, x, w, s, sl0)
     finally:
-        ctx.set_conv_halo_forward(True)
+        ctx.set_conv_halo(True)
     assert torch.equal(z, z0)
     zc = z.double().view(-1, 64)
     s1, s0 = sl.sum(0).cpu(), sl0.sum(0).cpu()
     assert ((s1[0] - zc.sum(0).cpu()).abs() <= 1e-6 * zc.abs().sum(0).cpu() + 1e-9).all()
     assert ((s1[1] - (zc * zc).sum(0).cpu()).abs() <= 1e-6 * (zc * zc).sum(0).cpu() + 1e-9).all()
     assert ((s1 - s0).abs() <= 2e-5 * s0.abs() + 1e-5).all()
+
+
+@pytest.mark.parametrize('B,H,ndy,bn', [(2, 32, 64, True), (3, 26, 64, True), (1, 76, 64, False), (2, 16, 64, True), (41, 32, 64, True), (2, 44, 64, False)])
+def test_halo_stride2_dgrad_is_bit_identical_to_the_tile_kernel(ctx, B, H, ndy, bn):
+    """fv_set_conv_halo, data-gradient side (dgrad9s2_mfma.hip: the stride-2 3x3 layer with 32 -> 64 channels): the four
+    parity classes from one dy halo tile with the transposed weights resident in LDS; same k-ordered chains as
+    conv_kernel<32,4,1> -> dx bit-identical (whole and ragged units, more units than workgroups); with the fused
+    BN-backward reduction the slots hold the same d-beta / d-gamma sums in another order, and match float64."""
+    from face_vijnana_yolov3_amd import ops
+    Ho = H // 2
+    w = _rand((64, 3, 3, 32), 101, -0.2, 0.2).cuda(); dy = _rand((B, Ho, Ho, ndy), 102).cuda()
+    z = (_rand((B, H, H, 32), 103) * 2 + 0.2).cuda()
+    gamma = _rand((32,), 104, 0.5, 1.5); beta = _rand((32,), 105)
+    zc = z.double().view(-1, 32)
+    mean = zc.mean(0); invstd = 1 / torch.sqrt(zc.var(0, unbiased=False) + 1e-3)
+    scale = (gamma.cuda().double() * invstd).float(); shift = (beta.cuda().double() - mean * scale.double()).float()
+    meanf, invf = mean.float(), invstd.float()
+
+    def run():
+        if not bn:
+            return ops.conv2d_dgrad(ctx, dy, w, (H, H), 2), None
+        sl = ops.stat_slots(32, 'cuda')
+        return ops.conv2d_dgrad_bnred(ctx, dy, w, (H, H), 2, z, scale, shift, meanf, invf, sl), sl
+    dx, sl = run()
+    ctx.set_conv_halo(False)
+    try:
+        dx0, sl0 = run()
+    finally:
+        ctx.set_conv_halo(True)
+    assert torch.equal(dx, dx0)
+    if bn:
+        s1, s0 = sl.sum(0).cpu(), sl0.sum(0).cpu()
+        g = dx.double().view(-1, 32)
+        gy = torch.where((z.view(-1, 32) * scale + shift) > 0, g, g * 0.1)          # the device's own branch decision
+        xhat = (z.view(-1, 32).double() - meanf.double()) * invf.double()
+        ref = torch.stack([gy.sum(0), (gy * xhat).sum(0)]).cpu()
+        mag = torch.stack([gy.abs().sum(0), (gy * xhat).abs().sum(0)]).cpu()
+        assert ((s1 - ref).abs() <= 2e-6 * mag + 1e-9).all(), (s1 - ref).abs().max().item()
+        assert ((s1 - s0).abs() <= 2e-5 * mag + 1e-6).all()
