@@ -125,5 +125,7 @@ struct FvWgradArgs {
 };
 int fv_wgrad_launch(fv_ctx* ctx, const FvWgradArgs& a);
 // wgrad9_mfma.hip: the nine taps of a 3x3 layer with 32 -> 64 channels in one workgroup (x halo + dy tile staged once)
+bool fv_wgrad0_ok(const FvWgradArgs& a);    // wgrad0_mfma.hip: the first layer (3 -> 32 channels)
+int fv_wgrad0_launch(fv_ctx* ctx, const FvWgradArgs& a);
 bool fv_wgrad9_ok(const FvWgradArgs& a);
 int fv_wgrad9_launch(fv_ctx* ctx, const FvWgradArgs& a);

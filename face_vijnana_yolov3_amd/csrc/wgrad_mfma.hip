@@ -528,6 +528,7 @@ int fv_wgrad_launch(fv_ctx* ctx, const FvWgradArgs& a) {
     if (a.Cin % 32 != 0) {
         FV_REQUIRE(ctx, 9 * a.Cin <= 32 && a.is == 1 && a.Hl == a.Hin && a.Wl == a.Win && a.taps.n == 9,
                    "wgrad: Cin=%d only supported as 3x3 stride-1 pad-1 with 9*Cin<=32", a.Cin);
+        if (ctx->wgrad_fused_taps && fv_wgrad0_ok(a)) return fv_wgrad0_launch(ctx, a);
         if (a.N > 32) return launch_w<64, 32, false, true>(ctx, a);
         return launch_w<32, 32, false, true>(ctx, a);
     }

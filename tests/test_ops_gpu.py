@@ -136,7 +136,27 @@ WGRAD_CASES = [
     (2, 20, 32, 64, 3, 2, 64),
     (1, 38, 32, 64, 3, 2, 128),
     (5, 4, 32, 64, 3, 1, 64),
+    # the first layer's halo kernel: whole / ragged units, padded dy, more units than workgroups, one-row images
+    (2, 32, 3, 32, 3, 1, 32),
+    (3, 13, 3, 32, 3, 1, 32),
+    (1, 70, 3, 32, 3, 1, 64),
+    (200, 8, 3, 32, 3, 1, 32),
+    (4, 1, 3, 32, 3, 1, 32),
 ]
+
+
+def test_first_layer_wgrad_halo_equals_gather(ctx):
+    """wgrad0_mfma.hip against the element-wise gather kernel (fv_set_wgrad_fused_taps(0)): same products, other summation order."""
+    from face_vijnana_yolov3_amd import ops
+    for (B, H) in [(3, 48), (2, 21)]:
+        x = _rand((B, H, H, 3), 83).cuda(); dy = _rand((B, H, H, 32), 84).cuda()
+        got = ops.conv2d_wgrad(ctx, x, dy, 32, 3, 1)
+        ctx.set_wgrad_fused_taps(False)
+        try:
+            ref = ops.conv2d_wgrad(ctx, x, dy, 32, 3, 1)
+        finally:
+            ctx.set_wgrad_fused_taps(True)
+        assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), (B, H)
 
 
 def test_wgrad_fused_taps_equals_generic(ctx):
