@@ -127,5 +127,7 @@ int fv_wgrad_launch(fv_ctx* ctx, const FvWgradArgs& a);
 // wgrad9_mfma.hip: the nine taps of a 3x3 layer with 32 -> 64 channels in one workgroup (x halo + dy tile staged once)
 bool fv_wgrad0_ok(const FvWgradArgs& a);    // wgrad0_mfma.hip: the first layer (3 -> 32 channels)
 int fv_wgrad0_launch(fv_ctx* ctx, const FvWgradArgs& a);
+bool fv_wgrad1_ok(const FvWgradArgs& a);    // wgrad1_mfma.hip: the 1x1 layer with 64 -> 32 channels, streaming
+int fv_wgrad1_launch(fv_ctx* ctx, const FvWgradArgs& a);
 bool fv_wgrad9_ok(const FvWgradArgs& a);
 int fv_wgrad9_launch(fv_ctx* ctx, const FvWgradArgs& a);

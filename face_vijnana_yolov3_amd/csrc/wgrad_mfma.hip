@@ -534,6 +534,7 @@ int fv_wgrad_launch(fv_ctx* ctx, const FvWgradArgs& a) {
     }
     FV_REQUIRE(ctx, a.taps.n >= 1 && a.taps.n <= 9, "wgrad: bad tap count");
     if (ctx->wgrad_fused_taps && fv_wgrad9_ok(a)) return fv_wgrad9_launch(ctx, a);
+    if (ctx->wgrad_fused_taps && fv_wgrad1_ok(a)) return fv_wgrad1_launch(ctx, a);
     if (a.N >= 128 && a.Cin % 128 == 0) return launch_w<128, 128, true, false>(ctx, a);
     const bool n64 = a.N > 32, c64 = a.Cin % 64 == 0;
     if (n64 && c64) return launch_w<64, 64, false, false>(ctx, a);

@@ -63,8 +63,9 @@ int fv_set_tail_split(fv_ctx* ctx, int on);
 int fv_set_conv_waves8(fv_ctx* ctx, int on);
 /* Weight-gradients of the early layers: 1 (default) the 3x3 layers with 32 input and 64 output channels (conv_1, conv_3) and the
  * first layer (3 -> 32) stage the x halo and the dy tile of a pixel unit once and multiply all nine taps from it
- * (wgrad9_mfma.hip, wgrad0_mfma.hip); 0 the generic kernels (one workgroup per tap / element-wise gather).  Same products,
- * different float-atomic summation order. */
+ * (wgrad9_mfma.hip, wgrad0_mfma.hip), the 1x1 layer with 64 -> 32 channels (conv_2) streams 128-pixel units (wgrad1_mfma.hip);
+ * 0 the generic kernels (one workgroup per tap / element-wise gather / 32-pixel chunks).  Same products, different
+ * float-atomic summation order. */
 int fv_set_wgrad_fused_taps(fv_ctx* ctx, int on);
 /* Halo-tile kernels for the 3x3 layers with 32 input and 64 output channels (conv_1, conv_3): 1 (default) the training-mode
  * forward (raw z + statistics slots; conv9_mfma.hip) and the stride-2 data-gradient with or without the fused BN-backward

@@ -142,6 +142,11 @@ WGRAD_CASES = [
     (1, 70, 3, 32, 3, 1, 64),
     (200, 8, 3, 32, 3, 1, 32),
     (4, 1, 3, 32, 3, 1, 32),
+    # the streaming 1x1 kernel (64 -> 32 channels): whole units, a ragged last unit, padded dy, fewer pixels than one unit
+    (2, 16, 64, 32, 1, 1, 64),
+    (3, 13, 64, 32, 1, 1, 32),
+    (1, 5, 64, 32, 1, 1, 32),
+    (9, 40, 64, 32, 1, 1, 32),
 ]
 
 
