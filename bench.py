@@ -52,17 +52,19 @@ TRAFFIC_FILES = ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--spawn', action='store_true', help='go through the self-launcher even for --gpus 1 (rehearsal of the N>1 start-up)')
+    ap.add_argument('--rendezvous-only', action='store_true', help='ranks only rendezvous, all-reduce one number and exit (launcher rehearsal)')
     ap.add_argument('--batch', type=int, default=PER_GPU_BATCH, help='per-GPU batch (default 40 = BASELINE config)')
     ap.add_argument('--image-size', type=int, default=IMAGE_SIZE)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=1)
+    ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-overlap', action='store_true', help='serialise wgrad on the main stream (A/B aid)')
     ap.add_argument('--no-tail-split', action='store_true', help='conv launches without the tail split (A/B aid)')
-    ap.add_argument('--fused-bn-backward', action='store_true', help='fv_set_fused_bn_backward(1) (A/B aid; measured slower)')
     ap.add_argument('--no-detect', action='store_true', help='skip the detect-path measurement (PMC passes)')
+    ap.add_argument('--no-rccl-rehearsal', action='store_true', help='N=1: skip the world-size-1 RCCL group rehearsal')
     ap.add_argument('--no-loader', action='store_true', help='skip the loader-inclusive measurement')
     ap.add_argument('--no-three-scale', action='store_true', help='skip the three-scale training measurement')
     ap.add_argument('--loader-steps', type=int, default=6)
@@ -90,7 +92,7 @@ def host_cpu():
     return model, len(cores) or None, os.cpu_count()
 
 
-def cpu_baseline(batch, image_size):
+def cpu_baseline(batch, image_size, budget_s=45.0):
     """Torch-CPU oracle (the reference's arithmetic restated, kind 'port') on this box's host cores, on a
     bounded sample: train step (fwd+bwd+Adam) at `batch` images, warm-up + timed samples; plus the detect
     path on the CPU: oracle forward at batch 1 and the single-core C oracle of decode + NMS + top-k."""
@@ -110,8 +112,24 @@ def cpu_baseline(batch, image_size):
         no.keras_adam(p, grad, m, v, 0, **{k: HPS[k] for k in ('lr', 'beta_1', 'beta_2')})
         return time.perf_counter() - t0
 
-    step(1, 128)                                   # warm-up: thread pool, allocator, oneDNN primitives
-    t_train = [step(batch, image_size) for _ in range(2)]
+    # thread sweep (128 threads at batch 1 ran the oracle at 10 GFLOP/s): the step at `batch` images with
+    # 32 / 64 / 128 torch threads (capped at the box's logical CPUs), best kept; bounded -- the sweep stops once `budget_s`
+    # seconds of timed CPU work have been spent
+    logical = os.cpu_count() or 8
+    sweep = sorted({min(t, logical) for t in (32, 64, 128)})
+    t_by_threads, spent = {}, 0.0
+    for nt in sweep:
+        torch.set_num_threads(nt)
+        step(1, 128)                               # warm-up: thread pool, allocator, oneDNN primitives
+        t = step(batch, image_size)
+        t_by_threads[nt] = t; spent += t
+        if spent > budget_s:
+            break
+    best_threads = min(t_by_threads, key=t_by_threads.get)
+    torch.set_num_threads(best_threads)
+    t_train = [t_by_threads[best_threads]]
+    if spent < budget_s:
+        t_train.append(step(batch, image_size))
     x1 = torch.rand((1, image_size, image_size, 3))
     with torch.no_grad():
         no.forward(p, st, x1, training=False)
@@ -127,11 +145,14 @@ def cpu_baseline(batch, image_size):
     t0 = time.perf_counter(); opp.detect_postproc(head, image_size, 0.5, 0.5, 60); t_pp = time.perf_counter() - t0
     model, phys, logical = host_cpu()
     best = min(t_train)
+    train_flops = 3 * no.fwd_flops_per_image(image_size) - 2 * image_size * image_size * 27 * 32
     return dict(value=round(batch / best, 4), unit='images/sec', cores=torch.get_num_threads(), kind='port',
                 cpu_model=model, physical_cores=phys, logical_cpus=logical,
-                samples_s=[round(t, 2) for t in t_train],
-                sample='train step (fwd+bwd+Adam) of the torch-CPU oracle at batch %d, %dx%d, fp32: 1 warm-up at 128x128 + %d timed '
-                       'samples, best taken; %d torch threads' % (batch, image_size, image_size, len(t_train), torch.get_num_threads()),
+                samples_s=[round(t, 2) for t in t_train], thread_sweep_s={str(k): round(v, 2) for k, v in t_by_threads.items()},
+                gflops=round(train_flops * batch / best / 1e9, 1),
+                sample='train step (fwd+bwd+Adam) of the torch-CPU oracle at batch %d, %dx%d, fp32: thread sweep %s (one timed step each '
+                       'after a 128x128 warm-up, bounded at %.0f s), best = %d threads, %d timed samples there, best taken'
+                       % (batch, image_size, image_size, sorted(t_by_threads), budget_s, best_threads, len(t_train)),
                 detect_cpu=dict(unit='ms/img', forward_batch1=round(min(t_fwd) * 1e3, 1), forward_threads=torch.get_num_threads(),
                                 postproc_c_oracle_1core=round(t_pp / nf * 1e3, 5),
                                 sample='oracle forward (inference BN) at batch 1, best of 3; C oracle decode+NMS+top-k over the %d '
@@ -260,6 +281,49 @@ def three_scale_bench(device, S, B=16, steps=3):
     return out
 
 
+def rccl_world1_rehearsal(eng, x, y, steps=5):
+    """N = 1 only: the data-parallel step with a REAL RCCL process group of one rank -- every gradient bucket and the BN state
+    go through dist.all_reduce (backend nccl = RCCL) on the communication stream, ordered by events against the backward pass,
+    exactly as on 8 GPUs.  Reported in `multi_gpu` so that the N = 1 line already shows the collective path alive."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from face_vijnana_yolov3_amd.parallel import DataParallelTrainer
+    if dist.is_initialized():
+        return None
+    try:
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=eng.dev)
+        tr = DataParallelTrainer(eng, world_size=1, rank=0, force_bucket_path=True)
+        for _ in range(2):
+            tr.train_on_batch(x, y, **HPS)
+        tr.time_comm = True
+        tr.comm_ms()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.train_on_batch(x, y, **HPS)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        n_coll = len(tr._comm_events) // steps
+        ar = tr.comm_ms() / steps
+        out = dict(rccl_ranks=dist.get_world_size(), backend=dist.get_backend(), bucket_mib=tr.bucket_bytes >> 20,
+                   gradient_mb=round(eng.n_params * 4 / 1e6, 2), collectives_per_step=n_coll + 1, allreduce_ms=round(ar, 3),
+                   ms_per_step=round(ms, 3), steps=steps,
+                   note='world-size-1 nccl group on this GPU: bucketed all_reduce calls on the comm stream overlapped with backward')
+        dist.destroy_process_group()
+        return out
+    except Exception as e:      # the headline number must not depend on this rehearsal
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:
+            pass
+        return dict(rccl_ranks=0, error='%s: %s' % (type(e).__name__, e))
+
+
 def pmc_traffic(B, S):
     """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes --
     only if the kernel sources are still the ones that were profiled (fingerprint recorded with the pass)."""
@@ -281,8 +345,40 @@ def pmc_traffic(B, S):
     return None, None
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as FRESH child processes through
+    torch.distributed.run (one process per GPU, RCCL rendezvous on 127.0.0.1) BEFORE this process makes any GPU call,
+    relay rank 0's JSON line on stdout (everything else goes to stderr) and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != '--spawn']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # this pool's driver only supports dmabuf IPC (RCCL needs it)
+    env['FV_BENCH_SELF_LAUNCHED'] = '1'
+    print('bench.py: starting %d ranks: %s' % (args.gpus, ' '.join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+    got = False
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            sys.stdout.write(line); sys.stdout.flush(); got = True
+        else:
+            sys.stderr.write(line); sys.stderr.flush()
+    rc = proc.wait()
+    if rc == 0 and not got:
+        print('bench.py: the ranks exited 0 without printing a result line', file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.spawn):
+        sys.exit(self_launch(args))              # nothing above touched the GPU: the children own the devices
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -290,11 +386,24 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if 'FV_BENCH_DEVICE' in os.environ:   # rehearsal aid: several ranks on one GPU (not a measurement)
         local_rank = int(os.environ['FV_BENCH_DEVICE'])
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
-                         '--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...' % (args.gpus, args.gpus))
+    if args.rendezvous_only:
+        # start-up rehearsal (tests/test_bench_launcher.py runs it with 2 ranks on CPU): rendezvous, one all-reduce, one line
+        backend = os.environ.get('FV_DIST_BACKEND', 'nccl' if torch.cuda.is_available() else 'gloo')
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            t = torch.ones(1, device='cuda') * (rank + 1)
+        else:
+            dist.init_process_group(backend)
+            t = torch.ones(1) * (rank + 1)
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({'metric': 'rendezvous-only', 'value': float(t.item()), 'n_gpus': world, 'backend': backend}), flush=True)
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     from face_vijnana_yolov3_amd import data
     from face_vijnana_yolov3_amd.engine import Engine, train_flops_per_image
@@ -306,8 +415,6 @@ def main():
         eng.ctx.set_overlap(False)
     if args.no_tail_split:
         eng.ctx.set_tail_split(False)
-    if args.fused_bn_backward:
-        eng.ctx.set_fused_bn_backward(True)
     trainer = DataParallelTrainer(eng, world_size=world, rank=rank)  # inits RCCL when world > 1
     B, S = args.batch, args.image_size
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
@@ -319,16 +426,23 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # per-step marks for the median: one event record per step on the launch stream (no host sync inside the region)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     trainer.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     trainer.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt = trainer.max_over_ranks(dt)
     loss_v = float(loss.item())
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = trainer.max_over_ranks(per_step[len(per_step) // 2] if len(per_step) % 2 else
+                                       0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2]))
 
     # ---- N > 1: what the communication costs (every rank measures, rank 0 reports all of them)
     multi = None
@@ -386,6 +500,8 @@ def main():
         three = None
         if world == 1 and not args.no_three_scale and not args.no_detect:
             three = three_scale_bench(local_rank, S)
+        if world == 1 and not args.no_rccl_rehearsal:
+            multi = rccl_world1_rehearsal(eng, x, y)
         dom_name, dom = dominant(prof)
         roofline = None
         traffic, traffic_source = pmc_traffic(B, S)
@@ -409,6 +525,7 @@ def main():
         out = {
             'metric': 'training images/sec (%dx%d bs=%d per GPU)' % (S, S, B), 'value': round(ips, 2), 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'median_ms_per_step': round(median_ms, 3), 'images_per_sec_at_median': round(world * B / (median_ms * 1e-3), 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'FaceDetector mode=train image_size=%d batch_size=%d per GPU, synthetic UCCS-shaped '
                                    'batch, random-init Darknet-53 base + %dx%dx6 head, MSE, Adam lr 1e-4 b1=b2=0.99' % (S, B, S // 32, S // 32),

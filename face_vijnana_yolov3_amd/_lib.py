@@ -62,10 +62,8 @@ def _declare(L):
     i32, i64, f32, f64, vp, sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, c_void_p, ctypes.c_size_t
     sig = {
         'fv_set_overlap': (i32, [vp, i32]),
-        'fv_set_conv_dma': (i32, [vp, i32]),
         'fv_set_tail_split': (i32, [vp, i32]),
         'fv_set_conv_scratch': (i32, [vp, vp, sz]),
-        'fv_set_fused_bn_backward': (i32, [vp, i32]),
         'fv_set_conv0_direct': (i32, [vp, i32]),
         'fv_set_conv_waves8': (i32, [vp, i32]),
         'fv_set_conv_halo': (i32, [vp, i32]),
@@ -98,9 +96,6 @@ def _declare(L):
         'fv_bn_act_slots': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, f32]),
         'fv_conv2d_dgrad_bnred': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, i32]),
         'fv_bn_bwd_slots': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp, i32, i32, vp, vp, vp]),
-        'fv_bn_bwd_coeff': (i32, [vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, vp, vp]),
-        'fv_conv2d_dgrad_fused': (i32, [vp, vp, vp, vp, f32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32]),
-        'fv_conv2d_wgrad_fused': (i32, [vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, i32, i32, vp]),
         'fv_mse_loss_grad': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
         'fv_fd_loss_grad': (i32, [vp, vp, vp, i32, i32, vp, vp]),
         'fv_letterbox': (i32, [vp, vp, i32, i32, i32, vp, ctypes.POINTER(ctypes.c_int32)]),
@@ -154,9 +149,6 @@ class Context:
     def set_overlap(self, on):
         self.check(lib().fv_set_overlap(self._h, 1 if on else 0), 'fv_set_overlap')
 
-    def set_conv_dma(self, on):
-        self.check(lib().fv_set_conv_dma(self._h, 1 if on else 0), 'fv_set_conv_dma')
-
     def set_tail_split(self, on):
         self.check(lib().fv_set_tail_split(self._h, 1 if on else 0), 'fv_set_tail_split')
 
@@ -174,9 +166,6 @@ class Context:
 
     def set_conv0_direct(self, on):
         self.check(lib().fv_set_conv0_direct(self._h, 1 if on else 0), 'fv_set_conv0_direct')
-
-    def set_fused_bn_backward(self, on):
-        self.check(lib().fv_set_fused_bn_backward(self._h, 1 if on else 0), 'fv_set_fused_bn_backward')
 
     def set_conv_scratch(self, tensor):
         """Lend device scratch (a torch tensor, kept alive here) to the per-operator conv calls."""

@@ -54,12 +54,6 @@ int fv_set_overlap(fv_ctx* ctx, int on) {
     return FV_OK;
 }
 
-int fv_set_conv_dma(fv_ctx* ctx, int on) {
-    if (!ctx) return FV_ERR_INVALID;
-    ctx->conv_dma = on != 0;
-    return FV_OK;
-}
-
 int fv_set_tail_split(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;
     ctx->tail_split = on != 0;
@@ -93,12 +87,6 @@ int fv_set_conv_halo(fv_ctx* ctx, int on) {
 int fv_set_conv0_direct(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;
     ctx->conv0_direct = on != 0;
-    return FV_OK;
-}
-
-int fv_set_fused_bn_backward(fv_ctx* ctx, int on) {
-    if (!ctx) return FV_ERR_INVALID;
-    ctx->fused_bn_bwd = on != 0;
     return FV_OK;
 }
 

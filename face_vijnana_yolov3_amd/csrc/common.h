@@ -23,7 +23,6 @@ struct fv_ctx {
     // backward-pass overlap: weight-gradient kernels run on a side stream next to the
     // data-gradient / BN-backward chain (fv_set_overlap)
     bool overlap = true;
-    bool conv_dma = false;   // fv_set_conv_dma: LDS-DMA operand staging variant of the conv kernel
     hipStream_t side = nullptr;
     hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr};
     // scratch for the conv tail split (conv.h); lent by the network-level entry points out of the
@@ -36,7 +35,6 @@ struct fv_ctx {
     bool wgrad_fused_taps = true;   // fv_set_wgrad_fused_taps: wgrad9_mfma.hip for the 32 -> 64 channel 3x3 layers
     bool conv_halo = true;      // fv_set_conv_halo: conv9_mfma.hip (training forward) and dgrad9s2_mfma.hip (stride-2 data-gradient) for the 32 -> 64 channel 3x3 layers
     bool conv0_direct = true;    // fv_set_conv0_direct: vector-FMA first layer (conv0_direct.hip) instead of the gather kernel
-    bool fused_bn_bwd = false;   // fv_set_fused_bn_backward: BN-backward apply folded into the consumers' operand loads
     ~fv_ctx();
 };
 

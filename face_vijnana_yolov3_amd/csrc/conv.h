@@ -11,40 +11,6 @@ struct FvTaps {
     int wslot[9];
 };
 
-// "Virtual" BN-backward operand: instead of a materialised dz = dL/d(pre-BN output) tensor, a kernel is given g = dL/d(activated
-// output) and the layer's pre-BN tensor z (same layout) plus a per-channel table, and forms
-//     dz = scale * ((g * leaky'(z*scale+shift) - dbm) - ((z - mean) * invstd) * dgm),     dbm = d-beta / rows, dgm = d-gamma / rows
-// while staging the operand -- bit for bit what bn_bwd_apply_slots_kernel would have written, so the separate apply pass
-// (12 B per element of HBM traffic, fully exposed) disappears.  Elements outside the image / problem stay zero.
-// tab: [C/4][6][4] floats -- for each group of four channels the six vectors scale, shift, mean, invstd, dbm, dgm as float4s
-// (one 96-byte run per thread and K step), written by bn_bwd_coeff_kernel.
-struct FvVirtDz {
-    const float* z;        // NULL: plain operand
-    const float* tab;
-    float leaky;
-};
-struct FvVirtVec { float4 sc, sh, mu, is, db, dg; };
-__device__ __forceinline__ FvVirtVec fv_virt_load(const float* tab, int c) {   // c % 4 == 0
-    const float4* t = reinterpret_cast<const float4*>(tab + (size_t)(c >> 2) * 24);
-    return FvVirtVec{t[0], t[1], t[2], t[3], t[4], t[5]};
-}
-// branch-free (the result is AND-ed with an all-ones / all-zeros mask): the instructions must stay in the basic block of the
-// MFMAs they are interleaved with; out-of-range rows were loaded as zeros, so the unmasked value is finite
-__device__ __forceinline__ float fv_virt_dz1(float g, float z, float sc, float sh, float mu, float is, float dbm, float dgm, float leaky) {
-    const float gl = g * leaky;
-    const float gy = (z * sc + sh) > 0.f ? g : gl;
-    return sc * (gy - dbm - (z - mu) * is * dgm);
-}
-__device__ __forceinline__ float4 fv_virt_dz4(const float4& g, const float4& z, const FvVirtVec& v, float leaky, bool ok) {
-    const unsigned m = ok ? 0xFFFFFFFFu : 0u;
-    float4 o;
-    o.x = __uint_as_float(__float_as_uint(fv_virt_dz1(g.x, z.x, v.sc.x, v.sh.x, v.mu.x, v.is.x, v.db.x, v.dg.x, leaky)) & m);
-    o.y = __uint_as_float(__float_as_uint(fv_virt_dz1(g.y, z.y, v.sc.y, v.sh.y, v.mu.y, v.is.y, v.db.y, v.dg.y, leaky)) & m);
-    o.z = __uint_as_float(__float_as_uint(fv_virt_dz1(g.z, z.z, v.sc.z, v.sh.z, v.mu.z, v.is.z, v.db.z, v.dg.z, leaky)) & m);
-    o.w = __uint_as_float(__float_as_uint(fv_virt_dz1(g.w, z.w, v.sc.w, v.sh.w, v.mu.w, v.is.w, v.db.w, v.dg.w, leaky)) & m);
-    return o;
-}
-
 enum { FV_EPI_AFFINE = 1, FV_EPI_LEAKY = 2, FV_EPI_ADD = 4, FV_EPI_STATS = 8, FV_EPI_BNRED = 16 };
 
 // Gather-convolution:  out[b, oh*os+oph, ow*os+opw, n] = sum_{t,c} x[b, oh*is+dh[t], ow*is+dw[t], c] * w[n][wslot[t]][c]
@@ -84,7 +50,6 @@ struct FvConvArgs {
     int ksplit;        // >1: blockIdx.y owns a slice of the K steps and stores its raw partial to out + y*split_stride
     long long split_stride;
     int oph[4], opw[4];
-    FvVirtDz virt;     // x is g, staged as dz (see FvVirtDz); virt.z == NULL: x is used as it is
     FvTaps taps[4];
 };
 
@@ -120,7 +85,6 @@ struct FvWgradArgs {
     int Tw;                // taps per output channel in dw
     int M;                 // B*Hl*Wl
     double alg_flops;      // algorithmic 2*MAC of this launch (profiling only)
-    FvVirtDz virt;         // dy is g, staged as dz (see FvVirtDz)
     FvTaps taps;
 };
 int fv_wgrad_launch(fv_ctx* ctx, const FvWgradArgs& a);

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NTH, 1) void conv9_fwd_kernel(const FvConvArgs a, i
 }  // namespace
 
 bool fv_conv9_fwd_ok(const FvConvArgs& a) {
-    if (a.Cin != CC || a.Nout != CN || a.Tw != 9 || a.nclass != 1 || a.ksplit > 1 || a.virt.z) return false;
+    if (a.Cin != CC || a.Nout != CN || a.Tw != 9 || a.nclass != 1 || a.ksplit > 1) return false;
     if (a.epi != FV_EPI_STATS || !a.stat_slots || a.stat_nslot < 1) return false;
     if ((a.is != 1 && a.is != 2) || a.os != 1 || a.Hout != a.Hl || a.Wout != a.Wl || a.oph[0] || a.opw[0]) return false;
     if (a.Hl * a.is != a.Hin || a.Wl * a.is != a.Win || a.taps[0].n != 9) return false;

@@ -110,14 +110,13 @@ __device__ __forceinline__ void stat_store(const FvConvArgs& a, int mt, int n, f
     }
 }
 
-template <int BN, int WAVES_M, int WAVES_N, bool GATHER, bool VIRT = false>
+template <int BN, int WAVES_M, int WAVES_N, bool GATHER>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const FvConvArgs a) {
     // NTH threads: 4 waves (2x2, each 64x64) or 8 waves (2x4, each 64x32: two more waves per SIMD to cover barriers and LDS latency)
     constexpr int NTH = 64 * WAVES_M * WAVES_N;
     constexpr int APT = BM * 8 / NTH;      // A-tile float4 loads per thread
     constexpr int RSTEP = NTH / 8;         // tile rows covered by one pass of the workgroup
-    static_assert(!(GATHER || VIRT) || NTH == 256, "gather / fused-operand paths are written for 4 waves");
-    static_assert(!(GATHER && VIRT), "the gathered first layer has no data-gradient");
+    static_assert(!GATHER || NTH == 256, "the gather path is written for 4 waves");
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int MB = WTM / 32, NB = WTN / 32;
     constexpr int BL = BN * 8 / NTH;  // B-tile float4 loads per thread
@@ -256,33 +255,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const F
         const int per = (nk + nslice - 1) / nslice;
         const int s_begin = (tail_part ? tail_q % a.tail_f : (int)blockIdx.y) * per;
         const int s_end = min(nk, s_begin + per);
-        // PD2 (the plain operand forms): the K loop is unrolled by two with two register sets -- step s issues the loads of step
-        // s + 2 into the set that was staged during step s - 1, and stages the set loaded during step s - 1.  The LDS buffer
-        // index becomes a compile-time constant and a staged row has been in its registers for a whole step.  Measured on
-        // MI355X (same box, 416x416 batch 40, ms per step of conv_kernel<128,2,4>): one set, rolled loop 28.9; one set,
-        // unrolled 28.8; this form 28.2; the same with branch-free (always issued, range-masked) loads and stores, which lets
-        // the loads of step s + 2 stay in flight across the staging point, 28.8 -- DESIGN.md 4.1.  -DFV_CONV_PD1: the rolled loop.
-#if defined(FV_CONV_PD1)
-        constexpr bool PD2 = false;
-#else
-        constexpr bool PD2 = !VIRT;
-#endif
-        u32x4 ra[APT], rb[BL];
-        u32x4 ra2[PD2 ? APT : 1], rb2[PD2 ? BL : 1];
-#if defined(FV_ABLATE_NOLOAD)
-        for (int p = 0; p < APT; ++p) ra[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
-        for (int p = 0; p < BL; ++p) rb[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
-        for (int p = 0; p < (PD2 ? APT : 1); ++p) ra2[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
-        for (int p = 0; p < (PD2 ? BL : 1); ++p) rb2[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
-#endif
-        // VIRT: x is g; the matching z rows and this K step's six per-channel vectors travel with the operand loads and the
-        // staged value is dz (FvVirtDz) -- zero where the tap is outside the image (a_off == OOB), like the plain operand
-        const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(VIRT ? a.virt.z : a.x), 0, (int)((unsigned)a.B * a.Hin * a.Win * a.Cin * 4u), 0x00020000);
-        u32x4 rz[VIRT ? 4 : 1];
-        FvVirtVec vv;
-        float4 tv[VIRT ? 4 : 1];   // transformed rows, formed between the MFMAs of chunks 1-2, written to LDS by stage()
-        unsigned st_off[APT];      // a_off of the loaded step
+        // The K loop is unrolled by two with two register sets -- step s issues the loads of step s + 2 into the set that was
+        // staged during step s - 1, and stages the set loaded during step s - 1.  The LDS buffer index becomes a compile-time
+        // constant and a staged row has been in its registers for a whole step.  Measured on MI355X (same box, 416x416 batch 40,
+        // ms per step of conv_kernel<128,2,4>): one set, rolled loop 28.9; one set, unrolled 28.8; this form 28.2; the same with
+        // branch-free (always issued, range-masked) loads and stores, which lets the loads of step s + 2 stay in flight across
+        // the staging point, 28.8 -- DESIGN.md 4.1.
+        u32x4 ra[APT], rb[BL], ra2[APT], rb2[BL];
         unsigned a_off[APT];
         int t = s_begin / cpk, ci = s_begin - t * cpk;
         auto set_tap = [&](int tp) {
@@ -295,86 +274,39 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const F
             }
         };
         auto load = [&]() {
-#if defined(FV_ABLATE_NOLOAD)
-            return;
-#endif
-#if defined(FV_ABLATE_SAMEADDR)
-            const int c0b = 0;
-            const int wofs = 0;
-#else
             const int c0b = ci * BK * 4;
             const int wofs = (taps.wslot[t] * a.Cin) * 4 + c0b;
-#endif
 #pragma unroll
             for (int p = 0; p < APT; ++p) ra[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, a_off[p], c0b, 0);
-            if constexpr (VIRT) {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) { rz[p] = __builtin_amdgcn_raw_buffer_load_b128(zr, a_off[p], c0b, 0); st_off[p] = a_off[p]; }
-                vv = fv_virt_load(a.virt.tab, ci * BK + col4);
-            }
 #pragma unroll
             for (int p = 0; p < BL; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_row[p], wofs, 0);
         };
-        auto transform = [&](int p) {   // VIRT only: row p of the loaded step -> tv[p]
-            if constexpr (VIRT) {
-                const float4 g = make_float4(__uint_as_float(ra[p].x), __uint_as_float(ra[p].y), __uint_as_float(ra[p].z), __uint_as_float(ra[p].w));
-                const float4 z = make_float4(__uint_as_float(rz[p].x), __uint_as_float(rz[p].y), __uint_as_float(rz[p].z), __uint_as_float(rz[p].w));
-                tv[p] = fv_virt_dz4(g, z, vv, a.virt.leaky, st_off[p] != OOB);
-            }
-        };
-        // pins tv[p] as computed HERE: without it the compiler sinks the whole transform into the `if (more)` block of stage(),
-        // behind the MFMAs it is meant to hide under
-        auto pin = [&](int p) {
-            if constexpr (VIRT) asm volatile("" : "+v"(tv[p].x), "+v"(tv[p].y), "+v"(tv[p].z), "+v"(tv[p].w));
-        };
         auto stage = [&](int buf) {
-            if constexpr (VIRT) {
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * p) * LDT + col4]) = tv[p];
-            } else {
 #pragma unroll
             for (int p = 0; p < APT; ++p)
                 *reinterpret_cast<u32x4*>(&As[buf][((tid >> 3) + RSTEP * p) * LDT + col4]) = ra[p];
-            }
 #pragma unroll
             for (int p = 0; p < BL; ++p)
                 *reinterpret_cast<u32x4*>(&Bs[buf][((tid >> 3) + RSTEP * p) * LDT + col4]) = rb[p];
         };
         auto advance = [&]() {
-#if defined(FV_ABLATE_SAMEADDR)
-            if (++ci == cpk) { ci = 0; ++t; }
-#else
             if (++ci == cpk) { ci = 0; ++t; if (t < taps.n) set_tap(t); }
-#endif
         };
-        auto load2 = [&]() {      // second register set (PD2)
-#if defined(FV_ABLATE_NOLOAD)
-            return;
-#endif
-            if constexpr (PD2) {
-#if defined(FV_ABLATE_SAMEADDR)
-                const int c0b = 0;
-                const int wofs = 0;
-#else
-                const int c0b = ci * BK * 4;
-                const int wofs = (taps.wslot[t] * a.Cin) * 4 + c0b;
-#endif
+        auto load2 = [&]() {      // second register set
+            const int c0b = ci * BK * 4;
+            const int wofs = (taps.wslot[t] * a.Cin) * 4 + c0b;
 #pragma unroll
-                for (int p = 0; p < APT; ++p) ra2[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, a_off[p], c0b, 0);
+            for (int p = 0; p < APT; ++p) ra2[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, a_off[p], c0b, 0);
 #pragma unroll
-                for (int p = 0; p < BL; ++p) rb2[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_row[p], wofs, 0);
-            }
+            for (int p = 0; p < BL; ++p) rb2[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_row[p], wofs, 0);
         };
         auto stage2 = [&](int buf) {
-            if constexpr (PD2) {
 #pragma unroll
-                for (int p = 0; p < APT; ++p)
-                    *reinterpret_cast<u32x4*>(&As[buf][((tid >> 3) + RSTEP * p) * LDT + col4]) = ra2[p];
+            for (int p = 0; p < APT; ++p)
+                *reinterpret_cast<u32x4*>(&As[buf][((tid >> 3) + RSTEP * p) * LDT + col4]) = ra2[p];
 #pragma unroll
-                for (int p = 0; p < BL; ++p)
-                    *reinterpret_cast<u32x4*>(&Bs[buf][((tid >> 3) + RSTEP * p) * LDT + col4]) = rb2[p];
-            }
+            for (int p = 0; p < BL; ++p)
+                *reinterpret_cast<u32x4*>(&Bs[buf][((tid >> 3) + RSTEP * p) * LDT + col4]) = rb2[p];
         };
         // fragment double-buffering: the LDS reads of K-chunk c+1 are issued before the MFMAs of
         // chunk c, and the next tile is staged into the other LDS buffer while chunks 2-3 compute
@@ -401,7 +333,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const F
                     }
         };
 
-        if constexpr (PD2) {
+        {
             if (s_begin < s_end) {
                 set_tap(t);
                 load(); advance();
@@ -436,62 +368,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const F
                 body(s, std::false_type{});
                 if (s + 1 < s_end) body(s + 1, std::true_type{});
             }
-        } else {
-        if (s_begin < s_end) {
-            set_tap(t);
-            load();
-#pragma unroll
-            for (int p = 0; p < 4; ++p) transform(p);
-            stage(0);
-            advance();
-        }
-        __syncthreads();
-        for (int s = s_begin; s < s_end; ++s) {
-            const int cur = (s - s_begin) & 1;
-            const bool more = s + 1 < s_end;
-            if (more) load();
-            float4 af0[MB], bf0[NB], af1[MB], bf1[NB];
-            // sched_barrier pins this order: left alone, the scheduler sinks the reads of chunks 2-3
-            // behind 31 of the first 32 MFMAs and then waits for them (and the stage writes) with the
-            // matrix pipe empty
-            readfrag(As[cur], Bs[cur], 0, af0, bf0);
-            readfrag(As[cur], Bs[cur], 1, af1, bf1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(af0, bf0);
-            __builtin_amdgcn_sched_barrier(0);
-            readfrag(As[cur], Bs[cur], 2, af0, bf0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(af1, bf1);
-            if constexpr (VIRT) {
-                // the operand transform rides in the issue gaps of these MFMAs (64 cycles each, 8 of them blocking the vector
-                // issue): one MFMA, then a handful of its VALU instructions, and so on -- placed as a block it costs the step 18 %
-                transform(0); transform(1);   // unconditional (one basic block with the MFMAs); unused after the last K step
-#pragma unroll
-                for (int i = 0; i < MB * NB * 4; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-                }
-                pin(0); pin(1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            readfrag(As[cur], Bs[cur], 3, af1, bf1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(af0, bf0);
-            if constexpr (VIRT) {
-                transform(2); transform(3);
-#pragma unroll
-                for (int i = 0; i < MB * NB * 4; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-                }
-                pin(2); pin(3);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) { stage(cur ^ 1); advance(); }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(af1, bf1);
-            __syncthreads();
-        }
         }
     }
 
@@ -687,210 +563,11 @@ __global__ __launch_bounds__(1024) void conv_tail_fixup_kernel(const FvConvArgs 
     }
 }
 
-// one wave instruction: 64 lanes x 16 B from per-lane buffer offsets to LDS at lds_base + lane*16
-// (the address-space cast only exists in the device pass)
-__device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t& rsrc, float* lds_base, unsigned voffset, int soffset) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, soffset, 0, 0);
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------
-// LDS-DMA variant (buffer_load_dwordx4 ... lds): operand tiles go HBM/L2 -> LDS without passing
-// through VGPRs.  One wave instruction writes 64 lanes x 16 B = 8 rows x 128 B contiguously, so the
-// LDS image is unpadded [row][32 floats]; bank conflicts of the ds_read_b128 fragment reads are
-// removed by an XOR swizzle of the 16-byte chunk position with ((row >> 1) & 7), applied on the
-// per-lane SOURCE address of the DMA and on the read address (CDNA4 guide rule 21).  Out-of-range
-// source offsets (padding taps, tail rows) deliver zeros.  Same tiling, K order and epilogue as
-// conv_kernel, so results are bit-identical.
-template <int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256, 2) void conv_kernel_dma(const FvConvArgs a) {
-    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
-    constexpr int MB = WTM / 32, NB = WTN / 32;
-    constexpr int BL = BN / 32;
-    constexpr int LD = BK;  // unpadded rows
-
-    __shared__ __attribute__((aligned(1024))) float As[2][BM * LD];
-    __shared__ __attribute__((aligned(1024))) float Bs[2][BN * LD];
-    __shared__ int rowoff[BM];
-    __shared__ float red[2][WAVES_M][BN];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int cls = blockIdx.z;
-    const FvTaps& taps = a.taps[cls];
-    const int NT = (a.Nout + BN - 1) / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = tile / NT, nt = tile - mt * NT;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int HWl = a.Hl * a.Wl;
-
-    if (tid < BM) {
-        int m = m0 + tid, off = -1;
-        if (m < a.M) {
-            int b = m / HWl, rem = m - b * HWl, oh = rem / a.Wl, ow = rem - oh * a.Wl;
-            off = ((b * a.Hout + oh * a.os + a.oph[cls]) * a.Wout + ow * a.os + a.opw[cls]) * a.Nout;
-        }
-        rowoff[tid] = off;
-    }
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    constexpr unsigned OOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.x, 0, (int)((unsigned)a.B * a.Hin * a.Win * a.Cin * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.w, 0, (int)((unsigned)a.Nout * a.Tw * a.Cin * 4u), 0x00020000);
-    // lane -> (row within the 8-row DMA group, chunk position); source chunk = position ^ swizzle(row)
-    const int csw = ((lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7)) * 4;   // floats
-    int a_pix[4], a_oh[4], a_ow[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        int m = m0 + (tid >> 3) + 32 * p;
-        if (m < a.M) {
-            int b = m / HWl, rem = m - b * HWl, oh = rem / a.Wl, ow = rem - oh * a.Wl;
-            a_pix[p] = b * a.Hin; a_oh[p] = oh * a.is; a_ow[p] = ow * a.is;
-        } else {
-            a_pix[p] = 0; a_oh[p] = -(1 << 28); a_ow[p] = 0;
-        }
-    }
-    unsigned b_row[BL];
-#pragma unroll
-    for (int p = 0; p < BL; ++p) {
-        int n = n0 + (tid >> 3) + 32 * p;
-        b_row[p] = n < a.Nout ? (unsigned)(n * a.Tw * a.Cin + csw) * 4u : OOB;
-    }
-    const int cpk = a.Cin / BK;
-    const int nk = taps.n * cpk;
-    const int per = (nk + a.ksplit - 1) / a.ksplit;
-    const int s_begin = blockIdx.y * per;
-    const int s_end = min(nk, s_begin + per);
-    unsigned a_off[4];
-    int t = s_begin / cpk, ci = s_begin - t * cpk;
-    auto set_tap = [&](int tp) {
-        const int dh = taps.dh[tp], dw = taps.dw[tp];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int ih = a_oh[p] + dh, iw = a_ow[p] + dw;
-            bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
-            a_off[p] = ok ? (unsigned)(((a_pix[p] + ih) * a.Win + iw) * a.Cin + csw) * 4u : OOB;
-        }
-    };
-    // wave w, instruction p covers rows [32p + 8w, 32p + 8w + 8): 1 KiB contiguous in the unpadded image
-    auto dma = [&](int buf) {
-        const int c0b = ci * BK * 4;
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            lds_dma16(xr, &As[buf][(32 * p + 8 * wave) * LD], a_off[p], c0b);
-        const int wofs = (taps.wslot[t] * a.Cin) * 4 + c0b;
-#pragma unroll
-        for (int p = 0; p < BL; ++p)
-            lds_dma16(wr, &Bs[buf][(32 * p + 8 * wave) * LD], b_row[p], wofs);
-    };
-    auto advance = [&]() {
-        if (++ci == cpk) { ci = 0; ++t; if (t < taps.n) set_tap(t); }
-    };
-    const int sw = ((lane & 31) >> 1) & 7;   // read-side swizzle of this lane's rows
-    const int arow = (wm * WTM + (lane & 31)) * LD, brow = (wn * WTN + (lane & 31)) * LD;
-    auto readfrag = [&](const float* __restrict__ Asm, const float* __restrict__ Bsm, int kc, float4 (&af)[MB], float4 (&bf)[NB]) {
-        const int pos = ((kc * 2 + (lane >> 5)) ^ sw) * 4;
-#pragma unroll
-        for (int i = 0; i < MB; ++i) af[i] = *reinterpret_cast<const float4*>(&Asm[arow + i * 32 * LD + pos]);
-#pragma unroll
-        for (int j = 0; j < NB; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bsm[brow + j * 32 * LD + pos]);
-    };
-    auto mfma_chunk = [&](const float4 (&af)[MB], const float4 (&bf)[NB]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const float av = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
-                    const float bv = e == 0 ? bf[j].x : e == 1 ? bf[j].y : e == 2 ? bf[j].z : bf[j].w;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-                }
-    };
-
-    if (s_begin < s_end) {
-        set_tap(t);
-        dma(0);
-        advance();
-    }
-    __syncthreads();   // drains the DMA (vmcnt) and orders it before the first fragment reads
-    for (int s = s_begin; s < s_end; ++s) {
-        const int cur = (s - s_begin) & 1;
-        if (s + 1 < s_end) { dma(cur ^ 1); advance(); }   // lands in the other buffer while this tile computes
-        float4 af0[MB], bf0[NB], af1[MB], bf1[NB];
-        readfrag(As[cur], Bs[cur], 0, af0, bf0);
-        readfrag(As[cur], Bs[cur], 1, af1, bf1);
-        mfma_chunk(af0, bf0);
-        readfrag(As[cur], Bs[cur], 2, af0, bf0);
-        mfma_chunk(af1, bf1);
-        readfrag(As[cur], Bs[cur], 3, af1, bf1);
-        mfma_chunk(af0, bf0);
-        mfma_chunk(af1, bf1);
-        __syncthreads();
-    }
-
-    const int half = lane >> 5, lc = lane & 31;
-    if (a.epi & FV_EPI_STATS) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { float v = acc[i][j][r]; s += v; q += v * v; }
-            s += __shfl_xor(s, 32);
-            q += __shfl_xor(q, 32);
-            if (half == 0) { red[0][wm][wn * WTN + j * 32 + lc] = s; red[1][wm][wn * WTN + j * 32 + lc] = q; }
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < a.Nout) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int w = 0; w < WAVES_M; ++w) { s += red[0][w][tid]; q += red[1][w][tid]; }
-            stat_store(a, mt, n0 + tid, s, q);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + lc;
-        const bool nv = n < a.Nout;
-        float sc = 1.0f, sh = 0.0f;
-        if ((a.epi & FV_EPI_AFFINE) && nv) {
-            if (a.scale) sc = a.scale[n];
-            if (a.shift) sh = a.shift[n];
-        }
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int off = rowoff[row];
-                if (off >= 0 && nv) {
-                    float v = acc[i][j][r];
-                    if (a.epi & FV_EPI_AFFINE) v = v * sc + sh;
-                    if (a.epi & FV_EPI_LEAKY) v = v > 0.0f ? v : v * a.leaky;
-                    if (a.epi & FV_EPI_ADD) v += a.addend[off + n];
-                    a.out[(size_t)blockIdx.y * a.split_stride + off + n] = v;
-                }
-            }
-    }
-}
-
-template <int BN, int WM_, int WN_, bool G, bool V = false>
+template <int BN, int WM_, int WN_, bool G>
 int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
     constexpr int NTH = 64 * WM_ * WN_;
     const int MT = (a.M + BM - 1) / BM, NT = (a.Nout + BN - 1) / BN;
     dim3 grid(MT * NT, a.ksplit > 1 ? a.ksplit : 1, a.nclass);
-    // (the BN-backward-applying instantiations are timed under the same names: same tiles, same role in the step)
     static const std::string name_s = "conv_kernel<" + std::to_string(BN) + "," + std::to_string(WM_) + "," + std::to_string(WN_) +
                                       (G ? ",true>" : ",false>");   // rocprofv3's name up to the first four template arguments
     static const char* name = name_s.c_str();
@@ -900,13 +577,6 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
     FvConvArgs b = a;
     if (b.ksplit < 1) b.ksplit = 1;
     b.tail_f = 1; b.tail_full = 0; b.tail_slab = nullptr;
-    if constexpr (!G && !V) {
-        if (ctx->conv_dma) {   // measured neutral against the register-staged kernel; opt-in
-            hipLaunchKernelGGL((conv_kernel_dma<BN, WM_, WN_>), grid, dim3(256), 0, ctx->stream, b);
-            FV_LAUNCH_CHECK(ctx);
-            return FV_OK;
-        }
-    }
     if constexpr (!G && BN == 128) {
         // tail split: only with caller scratch (network-level calls), whole-lattice launches, 16-byte rows
         if (ctx->tail_split && ctx->tail_slab && b.ksplit == 1 && a.nclass == 1 && (a.Nout & 3) == 0) {
@@ -915,7 +585,7 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
             if (tf > 1 && need <= ctx->tail_slab_floats) {
                 b.tail_f = tf; b.tail_full = full; b.tail_slab = ctx->tail_slab;
                 const int R = MT * NT - full;
-                hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G, V>), dim3(full + R * tf, 1, 1), dim3(NTH), 0, ctx->stream, b);
+                hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G>), dim3(full + R * tf, 1, 1), dim3(NTH), 0, ctx->stream, b);
                 FV_LAUNCH_CHECK(ctx);
                 hipLaunchKernelGGL((conv_tail_fixup_kernel<BN>), dim3(R), dim3(1024), 0, ctx->stream, b);
                 FV_LAUNCH_CHECK(ctx);
@@ -923,7 +593,7 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
             }
         }
     }
-    hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G, V>), grid, dim3(NTH), 0, ctx->stream, b);
+    hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G>), grid, dim3(NTH), 0, ctx->stream, b);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }
@@ -980,9 +650,8 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
     FV_REQUIRE(ctx, !(a.epi & FV_EPI_STATS) || (((a.psum && a.psq) || (a.stat_slots && a.stat_nslot >= 1)) && a.nclass == 1),
                "conv: stats need psum/psq or accumulator slots");
     FV_REQUIRE(ctx, !(a.epi & FV_EPI_ADD) || a.addend, "conv: FV_EPI_ADD needs addend");
-    FV_REQUIRE(ctx, !gather_cin(a.Cin) || !a.virt.z, "conv: the gathered first layer takes no BN-backward operand");
     FV_REQUIRE(ctx, !(a.epi & FV_EPI_BNRED) || (a.bn_z && a.bn_scale && a.bn_shift && a.bn_mean && a.bn_invstd && a.bn_slots &&
-                                                 a.bn_nslot >= 1 && (a.Nout & 3) == 0 && a.ksplit <= 1 && !ctx->conv_dma &&
+                                                 a.bn_nslot >= 1 && (a.Nout & 3) == 0 && a.ksplit <= 1 &&
                                                  !(a.epi & (FV_EPI_STATS | FV_EPI_AFFINE | FV_EPI_LEAKY))),
                "conv: fused BN-backward reduction needs its layer's tensors, 16-byte rows and a plain (+add) epilogue");
     FV_REQUIRE(ctx, a.ksplit <= 1 || (a.epi == 0 && a.nclass == 1 && a.Cin % BK == 0), "conv: split-K stores raw partials only");
@@ -1001,15 +670,9 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
     }
     for (int c = 0; c < a.nclass; ++c)
         FV_REQUIRE(ctx, a.taps[c].n >= 1 && a.taps[c].n <= 9, "conv: bad tap count");
-    if (a.virt.z) {
-        FV_REQUIRE(ctx, a.virt.tab && !ctx->conv_dma, "conv: the BN-backward operand needs its per-channel table (and the register-staged kernel)");
-        if (a.Nout > 64) return launch_cfg<128, 2, 2, false, true>(ctx, a);
-        if (a.Nout > 32) return launch_cfg<64, 2, 2, false, true>(ctx, a);
-        return launch_cfg<32, 4, 1, false, true>(ctx, a);
-    }
     // 128-wide tiles: 8 waves (2 x 4, each 64 x 32) put four waves on every SIMD instead of two: the same per-element fmaf
-    // chain (bit-identical outputs), 129 against 121 TF on the 52x52 layers; the LDS-DMA variant is written for 4 waves
-    if (a.Nout > 64) return ctx->conv_waves8 && !ctx->conv_dma ? launch_cfg<128, 2, 4, false>(ctx, a) : launch_cfg<128, 2, 2, false>(ctx, a);
-    if (a.Nout > 32) return ctx->conv_waves8 && !ctx->conv_dma ? launch_cfg<64, 4, 2, false>(ctx, a) : launch_cfg<64, 2, 2, false>(ctx, a);
+    // chain (bit-identical outputs), 129 against 121 TF on the 52x52 layers
+    if (a.Nout > 64) return ctx->conv_waves8 ? launch_cfg<128, 2, 4, false>(ctx, a) : launch_cfg<128, 2, 2, false>(ctx, a);
+    if (a.Nout > 32) return ctx->conv_waves8 ? launch_cfg<64, 4, 2, false>(ctx, a) : launch_cfg<64, 2, 2, false>(ctx, a);
     return launch_cfg<32, 4, 1, false>(ctx, a);
 }

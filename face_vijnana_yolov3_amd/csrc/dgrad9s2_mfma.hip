@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NTH, 1) void dgrad9s2_kernel(const FvConvArgs a, in
 }  // namespace
 
 bool fv_dgrad9s2_ok(const FvConvArgs& a) {
-    if (a.Cin != CD || a.Nout != CX || a.Tw != 9 || a.nclass != 4 || a.ksplit > 1 || a.virt.z) return false;
+    if (a.Cin != CD || a.Nout != CX || a.Tw != 9 || a.nclass != 4 || a.ksplit > 1) return false;
     if (a.epi & ~FV_EPI_BNRED) return false;
     if ((a.epi & FV_EPI_BNRED) && (!a.bn_z || !a.bn_slots || a.bn_nslot < 1)) return false;
     if (a.is != 1 || a.os != 2 || a.Hl != a.Hin || a.Wl != a.Win || a.Hout != 2 * a.Hin || a.Wout != 2 * a.Win) return false;

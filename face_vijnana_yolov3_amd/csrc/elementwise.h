@@ -14,9 +14,6 @@ int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale
                  const float* invstd, long long rows, int C, float leaky, float* pdb, float* pdg, float* dbeta, float* dgamma,
                  float* dz, double* slots = nullptr, int nslot = 0, bool reduced = false);
 // part != NULL: multi-workgroup form with fv_ew_mse_scratch_floats() floats of scratch (8-byte aligned); NULL: one workgroup
-// slot sums -> d-beta, d-gamma (gradient vector) and the [C/4][6][4] table of the fused backward (conv.h FvVirtDz)
-int fv_ew_bn_bwd_coeff(fv_ctx* ctx, const double* slots, int nslot, long long rows, int C, const float* scale, const float* shift,
-                       const float* mean, const float* invstd, float* dbeta, float* dgamma, float* tab);
 int fv_ew_mse(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int Cpad, float* loss, float* dy, float* dbias,
               double* part = nullptr);
 int fv_ew_mse_scratch_floats();

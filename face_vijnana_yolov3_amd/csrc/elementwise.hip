@@ -322,43 +322,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_slots_kernel(const float4* _
     }
 }
 
-// The slot sums alone, for the fused backward (conv.h FvVirtDz): d-beta / d-gamma into the gradient vector, and the per-channel
-// table [C/4][6][4] = (scale, shift, mean, invstd, dbm = d-beta / rows, dgm = d-gamma / rows) the operand-staging code of the
-// consumer kernels reads -- the same float values bn_bwd_apply_slots_kernel forms, so the fused and the separate path agree
-// bit for bit.
-__global__ __launch_bounds__(256) void bn_bwd_coeff_kernel(const double* __restrict__ slots, int nslot, int C, float inv_count,
-                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           float* __restrict__ dbeta, float* __restrict__ dgamma, float* __restrict__ tab) {
-    __shared__ double s_part[2][256];
-    const int tid = threadIdx.x;
-    auto finish = [&](int c, double a, double b) {
-        const float db = (float)a, dg = (float)b;
-        dbeta[c] = db; dgamma[c] = dg;
-        float* t = tab + (size_t)(c >> 2) * 24 + (c & 3);
-        t[0] = scale[c]; t[4] = shift[c]; t[8] = mean[c]; t[12] = invstd[c]; t[16] = db * inv_count; t[20] = dg * inv_count;
-    };
-    if (C >= 256) {
-        const int c = blockIdx.x * 256 + tid;
-        if (c < C) {
-            double a = 0.0, b = 0.0;
-            for (int k = 0; k < nslot; ++k) { a += slots[(size_t)(2 * k) * C + c]; b += slots[(size_t)(2 * k + 1) * C + c]; }
-            finish(c, a, b);
-        }
-    } else {
-        const int G = 256 / C, gi = tid / C, c = tid % C;
-        double a = 0.0, b = 0.0;
-        for (int k = gi; k < nslot; k += G) { a += slots[(size_t)(2 * k) * C + c]; b += slots[(size_t)(2 * k + 1) * C + c]; }
-        s_part[0][tid] = a; s_part[1][tid] = b;
-        __syncthreads();
-        if (tid < C) {
-            a = 0.0; b = 0.0;
-            for (int j = 0; j < G; ++j) { a += s_part[0][j * C + tid]; b += s_part[1][j * C + tid]; }
-            finish(tid, a, b);
-        }
-    }
-}
-
 // ---------------------------------------------------------------- MSE loss + gradient (single block, deterministic)
 // y_pred/y_true [rows][C]; dy padded [rows][Cpad] with zeros beyond C; bias gradient db[C] = column sums of dy.
 __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ yp, const float* __restrict__ yt, int rows, int C,
@@ -719,15 +682,6 @@ int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale
     FvProfScope ps(ctx, "bn_bwd_apply_kernel", 0.0, 12.0 * rows * C);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4, 256, 256 * 16)), dim3(256), 0, ctx->stream, (const float4*)g, (const float4*)z,
                        scale, shift, mean, invstd, dbeta, dgamma, (float)(1.0 / (double)rows), n4, C, leaky, (float4*)dz);
-    FV_LAUNCH_CHECK(ctx);
-    return FV_OK;
-}
-
-int fv_ew_bn_bwd_coeff(fv_ctx* ctx, const double* slots, int nslot, long long rows, int C, const float* scale, const float* shift,
-                       const float* mean, const float* invstd, float* dbeta, float* dgamma, float* tab) {
-    FV_REQUIRE(ctx, slots && nslot >= 1 && C % 4 == 0 && C <= 1024 && (C >= 256 || 256 % C == 0), "bn_bwd_coeff: bad slots / C");
-    hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(C >= 256 ? (C + 255) / 256 : 1), dim3(256), 0, ctx->stream, slots, nslot, C,
-                       (float)(1.0 / (double)rows), scale, shift, mean, invstd, dbeta, dgamma, tab);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }

@@ -68,11 +68,11 @@ struct Carver {
 
 struct Plan {
     int B, S, nl;
-    std::vector<float*> z, a, mean, invstd, scale, shift, wt, vtab;
+    std::vector<float*> z, a, mean, invstd, scale, shift, wt;
     std::vector<double*> slots, bslots;   // per layer [nslot][2][cout] fp64 accumulators, forward statistics and
                                           // backward d-beta/d-gamma (one contiguous range over all layers)
     size_t slots_bytes;
-    float *w0p, *yhat, *dyp, *G[5], *loss, *slab, *tail, *mse_part, *head_slab;
+    float *w0p, *yhat, *dyp, *G[4], *loss, *slab, *tail, *mse_part, *head_slab;
     int head_ks;
     size_t tail_floats;
     size_t bytes;
@@ -97,7 +97,6 @@ Plan make_plan(void* base, int B, int S, bool training) {
     Carver c(base);
     const int nb = p.nl - 1;
     p.z.resize(nb); p.a.resize(nb); p.mean.resize(nb); p.invstd.resize(nb); p.scale.resize(nb); p.shift.resize(nb);
-    p.vtab.resize(nb);
     p.wt.resize(p.nl);
     p.slots.resize(nb); p.bslots.resize(nb);
     size_t max_act = 0;
@@ -114,7 +113,7 @@ Plan make_plan(void* base, int B, int S, bool training) {
             const auto& d = N.L[l];
             p.scale[l] = sc_all ? sc_all + d.mean_off / 2 : nullptr;
             p.shift[l] = sh_all ? sh_all + d.mean_off / 2 : nullptr;
-            if (training) { p.mean[l] = c.take(d.cout); p.invstd[l] = c.take(d.cout); p.vtab[l] = c.take(6 * (size_t)d.cout); }
+            if (training) { p.mean[l] = c.take(d.cout); p.invstd[l] = c.take(d.cout); }
         }
     }
     p.w0p = c.take(32 * 32);
@@ -144,9 +143,9 @@ Plan make_plan(void* base, int B, int S, bool training) {
             }
         }
         p.dyp = c.take((size_t)B * G * G * HEAD_PAD);
-        // activation gradients g(l) = dL/d a(l): the one being consumed, the one being produced, the kept block gradient of a
-        // residual pair, and up to two more that a weight-gradient kernel on the side stream is still reading
-        for (int i = 0; i < 5; ++i) p.G[i] = c.take(max_act);
+        // G[0], G[1]: activation gradients g(l) = dL/d a(l) (the one being consumed / produced and the kept block gradient of a
+        // residual pair); G[2], G[3]: dz of the even / odd layers (a weight-gradient on the side stream may still read one)
+        for (int i = 0; i < 4; ++i) p.G[i] = c.take(max_act);
         p.loss = c.take(64);
         p.mse_part = c.take(fv_ew_mse_scratch_floats());
         // the head conv has 6 output channels: 53 tiles of 288 K steps -- K-split it like the batch-1 inference path
@@ -353,11 +352,6 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
     // every data-gradient also reduces d-beta / d-gamma of the layer whose output gradient it produces (conv.h
     // FV_EPI_BNRED): the BN-backward of that layer then is the apply pass alone (measured for every layer, also the
     // 32/64-channel ones: fusing all of them 59.4 ms per step, none 61.0).
-    // fv_set_fused_bn_backward(1) goes one step further: every consumer of dz(l) -- the weight-gradient and the
-    // data-gradient of layer l -- forms dz(l) from g(l) and z(l) while it stages its operand (conv.h FvVirtDz), and
-    // BatchNorm's backward has no pass of its own.  Bit-identical gradients, but MEASURED SLOWER on MI355X (63.7 against
-    // 58.7 ms per step: the apply pass costs 3.0 ms at 5.3 TB/s, the operand transform + second operand stream cost the
-    // matrix kernels 8 ms), so the separate pass stays the default.
     auto bnred = [&](int l, FvBnRed& b) -> const FvBnRed* {
         const auto& d = N.L[l];
         b = FvBnRed{p.z[l], p.scale[l], p.shift[l], p.mean[l], p.invstd[l], p.bslots[l], fv_ew_bn_stat_slots(d.cout), LEAKY};
@@ -366,22 +360,19 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
     FvBnRed bnr;
     if (int rc = fv_op_conv_dgrad(ctx, p.dyp, p.wt[nb], batch, G, G, h.cin, HEAD_PAD, 3, 1, nullptr, p.G[0], bnred(nb - 1, bnr))) return rc;
     if (on_bucket) on_bucket(user, h.w_off, (int64_t)HEAD_C * 9 * 1024 + HEAD_C);
-    // G[gcur]: g of the current layer; G[kept]: block gradient kept for the residual add; busy[par]: the buffer the
-    // weight-gradient of the last layer of that parity (side stream) may still be reading -- free again once ev_wg[par]
-    // has been waited for, which is also when that layer's gradient range is handed to the bucket callback.
+    // a layer's gradient range is handed to the bucket callback once ev_wg[parity] of its weight-gradient (side stream) has been
+    // waited for
     const bool ov = ctx->overlap && ctx->side;
     hipStream_t main_stream = ctx->stream;
     struct Pending { bool on; int64_t off, cnt; } pend[2] = {{false, 0, 0}, {false, 0, 0}};
-    int busy[2] = {-1, -1};
     auto join = [&](int par) -> int {
         if (!pend[par].on) return FV_OK;
         FV_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_wg[par], 0));
         if (on_bucket) on_bucket(user, pend[par].off, pend[par].cnt);
         pend[par].on = false;
-        busy[par] = -1;
         return FV_OK;
     };
-    if (!ctx->fused_bn_bwd) {
+    {
     // G[ig]: gradient w.r.t. the current layer's (post-add) output; G[ires]: kept block gradient.
     // dz(l) -> D[l&1].  The weight-gradient of layer l only needs dz(l) and the saved forward
     // activation, so it runs on the side stream while this stream continues with dgrad(l) and
@@ -422,44 +413,6 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
                                       bnred(l - 1, bnr))) return rc;
         ig = iout;
         if (d.role == 1) ires = -1;
-    }
-    } else {
-    int gcur = 0, kept = -1;
-    for (int l = nb - 1; l >= 0; --l) {
-        const auto& d = N.L[l];
-        const int H = S / d.in_div, Ho = S / d.out_div;
-        const long long rows = (long long)batch * Ho * Ho;
-        const int par = l & 1;
-        if (int rc = join(par)) return rc;
-        if (d.role == 2) kept = gcur;  // add(skip, x): the same gradient also reaches the skip input
-        if (int rc = fv_ew_bn_bwd_coeff(ctx, p.bslots[l], fv_ew_bn_stat_slots(d.cout), rows, d.cout, p.scale[l], p.shift[l], p.mean[l],
-                                        p.invstd[l], grads + d.beta_off, grads + d.gamma_off, p.vtab[l])) return rc;
-        const FvVirtDz vz{p.z[l], p.vtab[l], LEAKY};
-        const float* xin = l == 0 ? x : p.a[l - 1];
-        const int64_t cnt = (int64_t)d.cout * d.ksize * d.ksize * d.cin + 2 * d.cout;
-        if (ov) {
-            FV_HIP(ctx, hipEventRecord(ctx->ev_dz[par], main_stream));
-            FV_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_dz[par], 0));
-            ctx->stream = ctx->side;
-            int rc = fv_op_conv_wgrad(ctx, xin, p.G[gcur], batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off, &vz);
-            ctx->stream = main_stream;
-            if (rc) return rc;
-            FV_HIP(ctx, hipEventRecord(ctx->ev_wg[par], ctx->side));
-            pend[par] = Pending{true, d.w_off, cnt};
-            busy[par] = gcur;
-        } else {
-            if (int rc = fv_op_conv_wgrad(ctx, xin, p.G[gcur], batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off, &vz)) return rc;
-            if (on_bucket) on_bucket(user, d.w_off, cnt);
-        }
-        if (l == 0) break;
-        // the data-gradient reads G[gcur] through every tap while it writes g(l-1): another buffer, and not one that is kept or busy
-        int out = 0;
-        while (out == gcur || out == kept || out == busy[0] || out == busy[1]) ++out;
-        const float* addend = d.role == 1 ? p.G[kept] : nullptr;
-        if (int rc = fv_op_conv_dgrad(ctx, p.G[gcur], p.wt[l], batch, H, H, d.cin, d.cout, d.ksize, d.stride, addend, p.G[out],
-                                      bnred(l - 1, bnr), &vz)) return rc;
-        gcur = out;
-        if (d.role == 1) kept = -1;
     }
     }
     if (int rc = join(1)) return rc;   // layer 1, then layer 0: ranges stay in descending order

@@ -31,13 +31,12 @@ int fv_op_conv_forward(fv_ctx* ctx, const float* x, const float* w, int B, int H
 }
 
 int fv_op_conv_dgrad(fv_ctx* ctx, const float* dy, const float* w_t, int B, int H, int W, int cin, int cout_pad, int ksize,
-                     int stride, const float* addend, float* dx, const FvBnRed* bn, const FvVirtDz* virt) {
+                     int stride, const float* addend, float* dx, const FvBnRed* bn) {
     FV_REQUIRE(ctx, (ksize == 1 && stride == 1) || (ksize == 3 && (stride == 1 || stride == 2)), "dgrad: unsupported k=%d s=%d", ksize, stride);
     FV_REQUIRE(ctx, cout_pad % 32 == 0, "dgrad: cout_pad must be a multiple of 32");
     FV_REQUIRE(ctx, H % stride == 0 && W % stride == 0, "dgrad: H,W must be divisible by the stride");
     FvConvArgs a{};
     a.x = dy; a.w = w_t; a.out = dx; a.addend = addend;
-    if (virt) a.virt = *virt;
     a.B = B; a.Hin = H / stride; a.Win = W / stride; a.Cin = cout_pad;
     a.Hout = H; a.Wout = W; a.Nout = cin;
     a.is = 1; a.Tw = ksize * ksize;
@@ -86,11 +85,10 @@ int fv_op_conv_dgrad(fv_ctx* ctx, const float* dy, const float* w_t, int B, int 
 }
 
 int fv_op_conv_wgrad(fv_ctx* ctx, const float* x, const float* dy, int B, int H, int W, int cin, int cout, int dy_stride,
-                     int ksize, int stride, float* dw, const FvVirtDz* virt) {
+                     int ksize, int stride, float* dw) {
     FV_REQUIRE(ctx, (ksize == 1 && stride == 1) || (ksize == 3 && (stride == 1 || stride == 2)), "wgrad: unsupported k=%d s=%d", ksize, stride);
     FvWgradArgs a{};
     a.x = x; a.dy = dy; a.dw = dw;
-    if (virt) a.virt = *virt;
     a.B = B; a.Hin = H; a.Win = W; a.Cin = cin;
     a.Hl = H / stride; a.Wl = W / stride; a.N = cout; a.Ndy = dy_stride;
     a.is = stride; a.Tw = ksize * ksize; a.M = B * a.Hl * a.Wl;
@@ -209,36 +207,6 @@ int fv_bn_bwd_slots(fv_ctx* ctx, const float* g, const float* z, const float* sc
     FV_REQUIRE(ctx, g && z && scale && shift && mean && invstd && dbeta && dgamma && dz && rows > 0, "bn_bwd_slots: NULL buffer");
     return fv_ew_bn_bwd(ctx, g, z, scale, shift, mean, invstd, rows, C, leaky, nullptr, nullptr, dbeta, dgamma, dz, slots, nslot,
                         reduced != 0);
-}
-
-int fv_bn_bwd_coeff(fv_ctx* ctx, const double* slots, int nslot, int64_t rows, int C, const float* scale, const float* shift,
-                    const float* mean, const float* invstd, float* dbeta, float* dgamma, float* tab) {
-    if (!ctx) return FV_ERR_INVALID;
-    FV_REQUIRE(ctx, scale && shift && mean && invstd && dbeta && dgamma && tab && rows > 0, "bn_bwd_coeff: NULL buffer");
-    return fv_ew_bn_bwd_coeff(ctx, slots, nslot, rows, C, scale, shift, mean, invstd, dbeta, dgamma, tab);
-}
-
-int fv_conv2d_dgrad_fused(fv_ctx* ctx, const float* g, const float* z, const float* tab, float leaky, const float* w_t, int B, int H,
-                          int W, int cin, int cout_pad, int ksize, int stride, const float* addend, float* dx, const float* bn_z,
-                          const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_slots,
-                          int bn_nslot) {
-    if (!ctx) return FV_ERR_INVALID;
-    FV_REQUIRE(ctx, g && z && tab, "conv2d_dgrad_fused: NULL tensor");
-    const FvVirtDz vz{z, tab, leaky};
-    if (bn_z) {
-        if (int rc = slots_ok(ctx, bn_slots, bn_nslot, cin, "conv2d_dgrad_fused")) return rc;
-        FvBnRed b{bn_z, bn_scale, bn_shift, bn_mean, bn_invstd, bn_slots, bn_nslot, leaky};
-        return fv_op_conv_dgrad(ctx, g, w_t, B, H, W, cin, cout_pad, ksize, stride, addend, dx, &b, &vz);
-    }
-    return fv_op_conv_dgrad(ctx, g, w_t, B, H, W, cin, cout_pad, ksize, stride, addend, dx, nullptr, &vz);
-}
-
-int fv_conv2d_wgrad_fused(fv_ctx* ctx, const float* x, const float* g, const float* z, const float* tab, float leaky, int B, int H,
-                          int W, int cin, int cout, int ksize, int stride, float* dw) {
-    if (!ctx) return FV_ERR_INVALID;
-    FV_REQUIRE(ctx, g && z && tab, "conv2d_wgrad_fused: NULL tensor");
-    const FvVirtDz vz{z, tab, leaky};
-    return fv_op_conv_wgrad(ctx, x, g, B, H, W, cin, cout, cout, ksize, stride, dw, &vz);
 }
 
 int fv_mse_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int c_pad, float* loss, float* dy,

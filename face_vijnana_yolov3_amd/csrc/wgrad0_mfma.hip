@@ -137,8 +137,7 @@ __global__ __launch_bounds__(NTH, 3) void wgrad0_kernel(const FvWgradArgs a, int
 }  // namespace
 
 bool fv_wgrad0_ok(const FvWgradArgs& a) {
-    return a.Cin == CI && a.N == CN && a.Ndy >= CN && (a.Ndy & 3) == 0 && a.is == 1 && a.Hl == a.Hin && a.Wl == a.Win && a.taps.n == 9 &&
-           !a.virt.z;
+    return a.Cin == CI && a.N == CN && a.Ndy >= CN && (a.Ndy & 3) == 0 && a.is == 1 && a.Hl == a.Hin && a.Wl == a.Win && a.taps.n == 9;
 }
 
 int fv_wgrad0_launch(fv_ctx* ctx, const FvWgradArgs& a) {

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(NTH, 3) void wgrad1_kernel(const FvWgradArgs a, int
 
 bool fv_wgrad1_ok(const FvWgradArgs& a) {
     return a.Cin == CC && a.N == CN && a.Ndy >= CN && (a.Ndy & 3) == 0 && a.Tw == 1 && a.taps.n == 1 && a.is == 1 && a.Hl == a.Hin &&
-           a.Wl == a.Win && a.taps.dh[0] == 0 && a.taps.dw[0] == 0 && !a.virt.z;
+           a.Wl == a.Win && a.taps.dh[0] == 0 && a.taps.dw[0] == 0;
 }
 
 int fv_wgrad1_launch(fv_ctx* ctx, const FvWgradArgs& a) {

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(NTH, 1) void wgrad9_kernel(const FvWgradArgs a, int
 }  // namespace
 
 bool fv_wgrad9_ok(const FvWgradArgs& a) {
-    if (a.Cin != CC || a.N != CN || a.Ndy < CN || (a.Ndy & 3) || a.Tw != 9 || a.taps.n != 9 || a.virt.z) return false;
+    if (a.Cin != CC || a.N != CN || a.Ndy < CN || (a.Ndy & 3) || a.Tw != 9 || a.taps.n != 9) return false;
     if (a.is != 1 && a.is != 2) return false;
     if (a.Hl * a.is != a.Hin || a.Wl * a.is != a.Win) return false;
     for (int t = 0; t < 9; ++t)

@@ -25,7 +25,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KP = 32;  // pixels per chunk
 
 // NW = 8 (QUAD only): 512-thread workgroups, 2 x 4 waves of 64 x 32 -- four waves per SIMD instead of two, same arithmetic.
-template <int TM, int TN, bool QUAD, bool GATHER, bool VIRT = false, int NW = 4>
+template <int TM, int TN, bool QUAD, bool GATHER, int NW = 4>
 __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, int nsplit, int ntap_eff, int tiles_taps, int pinned) {
     static_assert(NW == 4 || (NW == 8 && QUAD && !GATHER), "8 waves: the 128x128 form only");
     constexpr int NTH = 64 * NW;
@@ -90,18 +90,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
         a_m[p] = ch_begin * KP + row;
         a_off[p] = (n0 + col < a.N) ? (unsigned)(n0 + col) * 4u : OOB;
     }
-    int b_b[BL], b_oh[BL], b_ow[BL], b_m[BL], b_col[BL];
     const int adv_b = KP / HWl, adv_h = (KP - adv_b * HWl) / a.Wl, adv_w = KP - adv_b * HWl - adv_h * a.Wl;
-    if constexpr (!GATHER) {
-#pragma unroll
-        for (int p = 0; p < BL; ++p) {
-            int f = tid + NTH * p, row = f / (TN / 4);
-            b_col[p] = (f % (TN / 4)) * 4;
-            int m = ch_begin * KP + row;
-            b_m[p] = m;
-            b_b[p] = m / HWl; int rem = m - b_b[p] * HWl; b_oh[p] = rem / a.Wl; b_ow[p] = rem - b_oh[p] * a.Wl;
-        }
-    }
     int g_m = 0, g_oh = 0, g_ow = 0, g_dh[4] = {0, 0, 0, 0}, g_dw[4] = {0, 0, 0, 0}, g_rel[4] = {0, 0, 0, 0};
     bool g_kv[4] = {false, false, false, false};
     if constexpr (GATHER) {
@@ -124,11 +113,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
     // the loads that use it; a load's address is one LDS read plus the lane's column.  dy rows are linear in the pixel index.
     // (Per-row arithmetic on the scalar unit was the first attempt: 60 scalar instructions per wave and chunk on the CU's single
     // scalar pipe recovered 4.5 %.)
-#if defined(FV_WGRAD_PREP) || defined(FV_WGRAD_VROW)
-    constexpr bool SROW = false;
-#else
     constexpr bool SROW = !GATHER;
-#endif
     constexpr int RPP = NTH / (TN / 4);                    // rows per pass of the workgroup
     __shared__ unsigned rowtab[2][KP];
     int t_oh = 0, t_ow = 0;
@@ -171,87 +156,14 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
     }
     int load_rel = 0;    // chunk (relative to ch_begin) the next load() fetches
     u32x4 ra[AL], rb[BL];
-    // VIRT: dy is g; the matching z rows are loaded beside it and the staged value is dz (conv.h FvVirtDz).  A thread keeps its
-    // four output channels over the whole pixel loop ((tid + 256 p) % (TM / 4) does not depend on p): six vectors, loaded once
-    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(VIRT ? a.virt.z : a.dy), 0, (int)((unsigned)a.M * a.Ndy * 4u), 0x00020000);
-    u32x4 rz[VIRT ? AL : 1];
-    float4 tv[VIRT ? AL : 1];
-    bool st_ok[AL];
-    FvVirtVec vv;
-    if constexpr (VIRT) {
-        const int n = n0 + (tid % (TM / 4)) * 4;
-        vv = fv_virt_load(a.virt.tab, n < a.N ? n : 0);     // channel groups outside N are masked by st_ok
-    }
-#if defined(FV_ABLATE_NOLOAD)
-    for (int p = 0; p < AL; ++p) ra[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
-    for (int p = 0; p < BL; ++p) rb[p] = u32x4{(unsigned)tid, 1u, 2u, 3u};
-#endif
-    // PREP: offsets of the next chunk computed between the MFMAs of the current one instead of in front of the chunk's first
-    // MFMA.  Measured neutral-to-slower on MI355X (tools/layer_bench.py, 7 shapes: wgrad sum 14.36 with, 14.15 ms without;
-    // without any loads 14.03, without the atomic epilogue 14.00): the per-chunk address arithmetic is not what the
-    // weight-gradient kernels wait for.  Kept behind a macro.
-#if defined(FV_WGRAD_PREP)
-    constexpr bool PREP = !GATHER;
-#else
-    constexpr bool PREP = false;
-#endif
-    unsigned offA[AL], offB[BL];
-    // prep(): byte offsets of the chunk to be loaded next (and the branch-free advance of the pixel coordinates) -- ~120 vector
-    // instructions per chunk that used to sit in front of the chunk's first MFMA; issue(): the loads themselves
-    auto prep = [&]() {
-#pragma unroll
-        for (int p = 0; p < AL; ++p) {
-            offA[p] = ((unsigned)a_m[p] * (unsigned)a.Ndy * 4u + a_off[p]) | (a_m[p] < a.M ? 0u : OOB);
-            a_m[p] += KP;
-        }
-        if constexpr (!GATHER) {
-#pragma unroll
-            for (int p = 0; p < BL; ++p) {
-                int ih = b_oh[p] * a.is + dh, iw = b_ow[p] * a.is + dw;
-                const bool ok = b_m[p] < a.M && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
-                offB[p] = ((unsigned)(((b_b[p] * a.Hin + ih) * a.Win + iw) * a.Cin + c0 + b_col[p]) * 4u) | (ok ? 0u : OOB);
-                b_m[p] += KP;
-                b_ow[p] += adv_w;
-                { const bool c = b_ow[p] >= a.Wl; b_ow[p] -= c ? a.Wl : 0; b_oh[p] += adv_h + (c ? 1 : 0); }
-                { const bool c = b_oh[p] >= a.Hl; b_oh[p] -= c ? a.Hl : 0; b_b[p] += adv_b + (c ? 1 : 0); }
-            }
-        }
-    };
-    auto pin_offsets = [&]() {
-#pragma unroll
-        for (int p = 0; p < AL; ++p) asm volatile("" : "+v"(offA[p]));
-#pragma unroll
-        for (int p = 0; p < BL; ++p) asm volatile("" : "+v"(offB[p]));
-    };
-    auto issue = [&]() {
-#if defined(FV_ABLATE_NOLOAD)
-        return;
-#endif
-#pragma unroll
-        for (int p = 0; p < AL; ++p) {
-            ra[p] = __builtin_amdgcn_raw_buffer_load_b128(yr, offA[p], 0, 0);
-            if constexpr (VIRT) { rz[p] = __builtin_amdgcn_raw_buffer_load_b128(zr, offA[p], 0, 0); st_ok[p] = (offA[p] & OOB) == 0; }
-        }
-#pragma unroll
-        for (int p = 0; p < BL; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, offB[p], 0, 0);
-    };
     auto load = [&]() {
-#if defined(FV_ABLATE_NOLOAD)
-        return;
-#endif
-        if constexpr (PREP) { issue(); return; }
 #pragma unroll
         for (int p = 0; p < AL; ++p) {
             // a_off carries the OOB bit for channel groups outside N; rows past M get it here (no branches)
             unsigned off;
-            if constexpr (SROW && !VIRT) { off = lin_a[p]; lin_a[p] += KP * (unsigned)a.Ndy * 4u; }
+            if constexpr (SROW) { off = lin_a[p]; lin_a[p] += KP * (unsigned)a.Ndy * 4u; }
             else off = ((unsigned)a_m[p] * (unsigned)a.Ndy * 4u + a_off[p]) | (a_m[p] < a.M ? 0u : OOB);
-#if defined(FV_ABLATE_SAMEADDR)
-            off = a_off[p] != OOB ? (unsigned)(tid / (TM / 4)) * (unsigned)a.Ndy * 4u + a_off[p] : OOB;
-#endif
             ra[p] = __builtin_amdgcn_raw_buffer_load_b128(yr, off, 0, 0);
-            if constexpr (VIRT) { rz[p] = __builtin_amdgcn_raw_buffer_load_b128(zr, off, 0, 0); st_ok[p] = a_m[p] < a.M && a_off[p] != OOB; }
             a_m[p] += KP;
         }
         if constexpr (GATHER) {
@@ -271,51 +183,18 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
             g_ow += adv_w;
             { const bool c = g_ow >= a.Wl; g_ow -= c ? a.Wl : 0; g_oh += adv_h + (c ? 1 : 0); }
             { const bool c = g_oh >= a.Hl; g_oh -= c ? a.Hl : 0; }
-        } else if constexpr (SROW) {
-#pragma unroll
-            for (int p = 0; p < BL; ++p) {
-                unsigned off = rowtab[load_rel & 1][RPP * p + tid / (TN / 4)] + lane_col;
-#if defined(FV_ABLATE_SAMEADDR)
-                off = (unsigned)((tid / (TN / 4)) * a.Cin) * 4u + lane_col;
-#endif
-                rb[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
-            }
-            ++load_rel;
         } else {
 #pragma unroll
-            for (int p = 0; p < BL; ++p) {
-                int ih = b_oh[p] * a.is + dh, iw = b_ow[p] * a.is + dw;
-                const bool ok = b_m[p] < a.M && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
-                unsigned off = ((unsigned)(((b_b[p] * a.Hin + ih) * a.Win + iw) * a.Cin + c0 + b_col[p]) * 4u) | (ok ? 0u : OOB);
-#if defined(FV_ABLATE_SAMEADDR)
-                off = (unsigned)((tid / (TN / 4)) * a.Cin + c0 + b_col[p]) * 4u;
-#endif
-                rb[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
-                // advance this row by KP pixels: branch-free carries (KP = adv_b images + adv_h rows + adv_w pixels)
-                b_m[p] += KP;
-                b_ow[p] += adv_w;
-                { const bool c = b_ow[p] >= a.Wl; b_ow[p] -= c ? a.Wl : 0; b_oh[p] += adv_h + (c ? 1 : 0); }
-                { const bool c = b_oh[p] >= a.Hl; b_oh[p] -= c ? a.Hl : 0; b_b[p] += adv_b + (c ? 1 : 0); }
-            }
+            for (int p = 0; p < BL; ++p)
+                rb[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, rowtab[load_rel & 1][RPP * p + tid / (TN / 4)] + lane_col, 0, 0);
+            ++load_rel;
         }
-    };
-    // VIRT: row p of the loaded chunk -> tv[p] (branch-free, placed between the MFMAs; conv.h FvVirtDz); pin() keeps it there
-    auto transform = [&](int p) {
-        if constexpr (VIRT) {
-            const float4 g = make_float4(__uint_as_float(ra[p].x), __uint_as_float(ra[p].y), __uint_as_float(ra[p].z), __uint_as_float(ra[p].w));
-            const float4 z = make_float4(__uint_as_float(rz[p].x), __uint_as_float(rz[p].y), __uint_as_float(rz[p].z), __uint_as_float(rz[p].w));
-            tv[p] = fv_virt_dz4(g, z, vv, a.virt.leaky, st_ok[p]);
-        }
-    };
-    auto pin = [&](int p) {
-        if constexpr (VIRT) asm volatile("" : "+v"(tv[p].x), "+v"(tv[p].y), "+v"(tv[p].z), "+v"(tv[p].w));
     };
     auto stage = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < AL; ++p) {
             int f = tid + NTH * p, row = f / (TM / 4), col = (f % (TM / 4)) * 4;
-            if constexpr (VIRT) *reinterpret_cast<float4*>(&As[buf][row * LDA + col]) = tv[p];
-            else *reinterpret_cast<u32x4*>(&As[buf][row * LDA + col]) = ra[p];
+            *reinterpret_cast<u32x4*>(&As[buf][row * LDA + col]) = ra[p];
         }
         if constexpr (GATHER) {
             *reinterpret_cast<u32x4*>(&Bs[buf][(tid >> 3) * LDB + (tid & 7) * 4]) = rb[0];
@@ -351,11 +230,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
     // U2 (plain operand forms): the chunk loop unrolled by two, so that the LDS buffer index is a compile-time constant
     // (wgrad_kernel<128,128,quad>: 13.86 -> 13.67 ms per step on MI355X; a second register set with the loads two chunks ahead,
     // the form the forward kernel uses, measured 13.85 with branches and 14.4 branch-free; the split forms are neutral)
-#if defined(FV_WGRAD_PREP) || defined(FV_WGRAD_ROLLED)
-    constexpr bool U2 = false;
-#else
-    constexpr bool U2 = !GATHER && !VIRT;
-#endif
+    constexpr bool U2 = !GATHER;
     if constexpr (U2) {
         load();
         stage(0);
@@ -385,20 +260,14 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
             if (ch + 1 < ch_end) body(ch + 1, std::true_type{});
         }
     } else {
-    if constexpr (PREP) prep();
+    // the gathered first layer: rolled chunk loop, the next chunk staged mid-chunk
     load();
-#pragma unroll
-    for (int p = 0; p < AL; ++p) transform(p);
     stage(0);
-    if constexpr (PREP) prep();     // offsets of chunk ch_begin + 1
     __syncthreads();
-    // the next chunk is staged mid-chunk; with the fused operand its rows are transformed one per k-pair pair before that
-    constexpr int IS = (VIRT && QUAD) ? 10 : NP / 2;
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int cur = (ch - ch_begin) & 1;
         const bool more = ch + 1 < ch_end;
         if (more) load();
-        publish_rows(ch - ch_begin + 2);
         float af0[MB], bf0[NB], af1[MB], bf1[NB];
         readfrag(As[cur], Bs[cur], 0, af0, bf0);
 #pragma unroll
@@ -408,37 +277,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
             readfrag(As[cur], Bs[cur], 2 * (i + 1), af1, bf1);
             __builtin_amdgcn_sched_barrier(0);
             mfma(af0, bf0);
-            if constexpr (PREP) {
-                if (i == (QUAD ? 12 : 0)) {   // after this chunk's loads were issued and (QUAD) after the staging of the next one
-                    prep();
-#pragma unroll
-                    for (int q = 0; q < MB * NB; ++q) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-                    }
-                    pin_offsets();
-                }
-            }
-            if constexpr (VIRT) {
-                if (QUAD ? (i >= 2 && i <= 8) : (i == IS)) {
-                    if constexpr (QUAD) transform((i - 2) / 2);
-                    else {
-#pragma unroll
-                        for (int p = 0; p < AL; ++p) transform(p);
-                    }
-#pragma unroll
-                    for (int q = 0; q < MB * NB; ++q) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
-                    }
-                    if constexpr (QUAD) pin((i - 2) / 2);
-                    else {
-#pragma unroll
-                        for (int p = 0; p < AL; ++p) pin(p);
-                    }
-                }
-            }
-            if (i == IS) { if (more) stage(cur ^ 1); }   // next tile lands in the other buffer mid-chunk
+            if (i == NP / 2) { if (more) stage(cur ^ 1); }   // next tile lands in the other buffer mid-chunk
             if (i + 2 < NP) readfrag(As[cur], Bs[cur], 2 * (i + 2), af0, bf0);
             __builtin_amdgcn_sched_barrier(0);
             mfma(af1, bf1);
@@ -447,9 +286,6 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
     }
     }
 
-#if defined(FV_ABLATE_NOATOMIC)
-    if (acc[0][0][0] != 12345.678f) return;   // ablation: no accumulation epilogue (keeps the MFMAs alive)
-#endif
     const int half = lane >> 5, lc = lane & 31;
     const int Kw = GATHER ? 9 * a.Cin : 0;
 #pragma unroll
@@ -472,8 +308,6 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
 
 template <int TM, int TN, bool QUAD, bool GATHER>
 int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
-    if (a.virt.z)
-        FV_REQUIRE(ctx, a.virt.tab && a.N % 4 == 0, "wgrad: the BN-backward operand needs its per-channel table and N %% 4 == 0");
     const int ntap = GATHER ? 1 : a.taps.n;
     const int tiles = ((a.N + TM - 1) / TM) * (GATHER ? 1 : a.Cin / TN) * ntap;
     const int total_chunks = (a.M + KP - 1) / KP;
@@ -505,11 +339,9 @@ int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
     FvProfScope ps(ctx, name, a.alg_flops,
                    4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.M * a.N + (double)a.N * a.Tw * a.Cin));
     const int nsplit8 = pinned ? (nsplit + 7) / 8 * 8 : nsplit;   // padded splits return at once (no chunks)
-    if (a.virt.z)
-        hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER, true>), dim3(tiles * nsplit8), dim3(256), 0, ctx->stream, a, nsplit, ntap, tiles, pinned);
-    else if constexpr (QUAD) {
+    if constexpr (QUAD) {
         if (ctx->conv_waves8)
-            hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER, false, 8>), dim3(tiles * nsplit8), dim3(512), 0, ctx->stream, a, nsplit, ntap, tiles, pinned);
+            hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER, 8>), dim3(tiles * nsplit8), dim3(512), 0, ctx->stream, a, nsplit, ntap, tiles, pinned);
         else
             hipLaunchKernelGGL((wgrad_kernel<TM, TN, QUAD, GATHER>), dim3(tiles * nsplit8), dim3(256), 0, ctx->stream, a, nsplit, ntap, tiles, pinned);
     } else

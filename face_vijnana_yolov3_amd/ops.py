@@ -152,41 +152,6 @@ def bn_bwd_slots(ctx, g, z, scale, shift, mean, invstd, slots, reduced, leaky=0.
     return dz, dgamma, dbeta
 
 
-def bn_bwd_coeff(ctx, slots, rows, scale, shift, mean, invstd):
-    """slot sums -> (dbeta, dgamma, tab): d-beta, d-gamma and the [C/4][6][4] table of the fused backward."""
-    C = scale.numel()
-    dbeta = torch.empty(C, dtype=torch.float32, device=slots.device); dgamma = torch.empty_like(dbeta)
-    tab = torch.empty((C // 4, 6, 4), dtype=torch.float32, device=slots.device)
-    ctx.check(lib().fv_bn_bwd_coeff(ctx.handle, ptr(slots), slots.shape[0], rows, C, ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
-                                    ptr(dbeta), ptr(dgamma), ptr(tab)), 'fv_bn_bwd_coeff')
-    return dbeta, dgamma, tab
-
-
-def conv2d_dgrad_fused(ctx, g, z, tab, w, in_hw, stride=1, addend=None, leaky=0.1, bnred=None):
-    """dgrad with dy = dz formed on the fly from (g, z, tab).  bnred = (bn_z, scale, shift, mean, invstd, slots)
-    of the layer below, or None."""
-    B = g.shape[0]
-    H, W = in_hw
-    cout, k, _, cin = w.shape
-    wt = transpose_weights(ctx, w, g.shape[3])
-    dx = torch.empty((B, H, W, cin), dtype=torch.float32, device=g.device)
-    bn = [NULL] * 5 + [NULL, 0] if bnred is None else [ptr(t) for t in bnred[:5]] + [ptr(bnred[5]), bnred[5].shape[0]]
-    rc = lib().fv_conv2d_dgrad_fused(ctx.handle, ptr(g.contiguous()), ptr(z.contiguous()), ptr(tab), leaky, ptr(wt), B, H, W, cin,
-                                     g.shape[3], k, stride, _p(addend), ptr(dx), *bn)
-    ctx.check(rc, 'fv_conv2d_dgrad_fused')
-    return dx
-
-
-def conv2d_wgrad_fused(ctx, x, g, z, tab, ksize, stride=1, leaky=0.1):
-    B, H, W, cin = x.shape
-    cout = g.shape[3]
-    dw = torch.zeros((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
-    rc = lib().fv_conv2d_wgrad_fused(ctx.handle, ptr(x.contiguous()), ptr(g.contiguous()), ptr(z.contiguous()), ptr(tab), leaky,
-                                     B, H, W, cin, cout, ksize, stride, ptr(dw))
-    ctx.check(rc, 'fv_conv2d_wgrad_fused')
-    return dw
-
-
 def mse_loss_grad(ctx, yp, yt, c_pad=32):
     C = yp.shape[-1]
     rows = yp.numel() // C

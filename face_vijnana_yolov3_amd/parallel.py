@@ -71,8 +71,10 @@ class DataParallelTrainer(object):
             self.comm = torch.cuda.Stream(device=engine.dev)
             engine.ensure_optimizer()
             self.reducer = BucketReducer(engine.grads, self.world, bucket_bytes, self._launch)
+        self._own_group = False
         if self.world > 1:
             if not dist.is_initialized():
+                self._own_group = True
                 os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
                 os.environ.setdefault('MASTER_PORT', '29500')
                 backend = os.environ.get('FV_DIST_BACKEND', 'nccl')  # 'nccl' IS RCCL on ROCm; gloo only to rehearse on one GPU
@@ -80,6 +82,12 @@ class DataParallelTrainer(object):
                     dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=engine.dev)
                 else:
                     dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+        # The collectives run whenever a process group exists -- also a group of ONE rank (a `nccl` group of world size 1 on a
+        # single GPU sends every bucket through RCCL on the comm stream: the hardware rehearsal of the N > 1 path).
+        self.collective = dist.is_available() and dist.is_initialized()
+        if self.collective and dist.get_world_size() != self.world:
+            raise RuntimeError('process group has %d ranks, trainer was told %d' % (dist.get_world_size(), self.world))
+        if self.collective:
             # identical start on every rank
             dist.broadcast(engine.params, 0)
             dist.broadcast(engine.state, 0)
@@ -91,7 +99,7 @@ class DataParallelTrainer(object):
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(ev)
             view.mul_(self._weight)            # n_rank / n_total: SUM over ranks = gradient of the merged-batch mean
-            if self.world > 1:
+            if self.collective:
                 t0 = None
                 if self.time_comm:
                     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
@@ -125,7 +133,7 @@ class DataParallelTrainer(object):
             # order); we keep ranks identical by averaging (parity unpinned)
             ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(eng.dev))
             self.comm.wait_event(ev)
-            if self.world > 1:
+            if self.collective:
                 dist.all_reduce(eng.state, op=dist.ReduceOp.SUM)
             eng.state.mul_(1.0 / self.world)
         torch.cuda.current_stream(eng.dev).wait_stream(self.comm)
@@ -133,20 +141,21 @@ class DataParallelTrainer(object):
         return loss
 
     def barrier(self):
-        if self.world > 1:
+        if self.collective:
             dist.barrier()
 
     def max_over_ranks(self, value):
-        if self.world == 1:
+        if not self.collective:
             return value
         t = torch.tensor([value], dtype=torch.float64, device=self.eng.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def shutdown(self):
-        if self.world > 1 and dist.is_initialized():
+        if self.collective and dist.is_initialized():
             dist.barrier()
-            dist.destroy_process_group()
+            if self._own_group:
+                dist.destroy_process_group()
 
 
 def slice_batch(n, world_size, rank):

@@ -48,9 +48,6 @@ int fv_set_stream(fv_ctx* ctx, void* stream);
  * of a gradient range (fv_bucket_fn) and before it returns.  on = 0 serialises everything on the
  * context's stream (default: on). */
 int fv_set_overlap(fv_ctx* ctx, int on);
-/* Conv operand staging through LDS-DMA (buffer_load ... lds, XOR-swizzled unpadded LDS image)
- * instead of VGPR staging.  Bit-identical results; measured neutral on MI355X (default: off). */
-int fv_set_conv_dma(fv_ctx* ctx, int on);
 /* Tail split of the conv launches inside fv_train_step / fv_forward_infer: when the 128x128 output
  * tiles of a layer do not fill a whole number of rounds of the 512 resident workgroup slots, the
  * tiles of the last partial round are cut into K slices (one workgroup each) whose partial tiles a
@@ -84,11 +81,6 @@ int fv_set_bn_zero_debias_step(fv_ctx* ctx, long long step);
 /* First layer (3 -> 32 channels, K = 27, HBM-bound): 1 (default) a direct vector-FMA kernel with an LDS halo tile
  * whenever W % 32 == 0 and H % 8 == 0; 0 the matrix-core gather kernel.  Bit-identical outputs (same fmaf chain). */
 int fv_set_conv0_direct(fv_ctx* ctx, int on);
-/* fv_train_step's BatchNorm backward.  0 (default): one pass per layer writes dz (the d-beta / d-gamma sums come
- * from the epilogue of the data-gradient above it).  1: no pass at all -- the weight- and data-gradient kernels of
- * the layer form dz from (g, z) while staging their operand (fv_conv2d_dgrad_fused / fv_conv2d_wgrad_fused).
- * Bit-identical gradients; measured slower on MI355X (63.7 vs 58.7 ms per step), kept as a switch. */
-int fv_set_fused_bn_backward(fv_ctx* ctx, int on);
 /* The per-operator conv entry points (fv_conv2d_forward / fv_conv2d_dgrad) have no workspace
  * argument; a caller that wants the tail split there lends device scratch here (NULL, 0 = none;
  * 64 MiB covers every Darknet-53 shape at batch 40).  The buffer must stay valid until the calls that
@@ -260,27 +252,6 @@ int fv_conv2d_dgrad_bnred(fv_ctx* ctx, const float* dy, const float* w_t, int B,
 int fv_bn_bwd_slots(fv_ctx* ctx, const float* g, const float* z, const float* scale, const float* shift,
                     const float* mean, const float* invstd, int64_t rows, int C, float leaky, double* slots,
                     int nslot, int reduced, float* dbeta, float* dgamma, float* dz);
-/* ---- BatchNorm's backward without a pass of its own (what fv_train_step runs): the consumers of
- * dz = dL/d(pre-BN output) take g = dL/d(activated output) and z instead and form, while staging their
- * operand between matrix instructions,
- *     dz = scale*((g*leaky'(z*scale+shift) - dbm) - ((z-mean)*invstd)*dgm)
- * -- bit for bit what fv_bn_bwd_slots writes.  fv_bn_bwd_coeff turns the slot sums into d-beta, d-gamma
- * and the per-channel table `tab` [C/4][6][4] floats: for each group of four channels the float4s
- * scale, shift, mean, invstd, dbm = d-beta/rows, dgm = d-gamma/rows. */
-int fv_bn_bwd_coeff(fv_ctx* ctx, const double* slots, int nslot, int64_t rows, int C, const float* scale,
-                    const float* shift, const float* mean, const float* invstd, float* dbeta, float* dgamma,
-                    float* tab);
-/* fv_conv2d_dgrad with dy given as (g, z, tab of the layer the conv belongs to: cout_pad channels).
- * bn_z != NULL additionally runs the fused d-beta/d-gamma reduction of the layer below, exactly as
- * fv_conv2d_dgrad_bnred (its vectors are [cin]). */
-int fv_conv2d_dgrad_fused(fv_ctx* ctx, const float* g, const float* z, const float* tab, float leaky,
-                          const float* w_t, int B, int H, int W, int cin, int cout_pad, int ksize, int stride,
-                          const float* addend, float* dx, const float* bn_z, const float* bn_scale,
-                          const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_slots,
-                          int bn_nslot);
-/* fv_conv2d_wgrad with dy given the same way (cout % 4 == 0, dy_stride == cout). */
-int fv_conv2d_wgrad_fused(fv_ctx* ctx, const float* x, const float* g, const float* z, const float* tab,
-                          float leaky, int B, int H, int W, int cin, int cout, int ksize, int stride, float* dw);
 /* loss = mean((yp-yt)^2) over [rows][C]; dy [rows][c_pad] = 2(yp-yt)/(rows*C) zero padded;
  * dbias[C] = column sums of dy (may be NULL). */
 int fv_mse_loss_grad(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int c_pad,

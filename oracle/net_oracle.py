@@ -282,7 +282,7 @@ def yolov3_init(seed=11, nclass_ch=255, dtype=torch.float32):
     return p.to(dtype), st.to(dtype)
 
 
-def yolov3_forward(params, state, x_nhwc, nclass_ch=255, training=False, positive=None, new_state=None):
+def yolov3_forward(params, state, x_nhwc, nclass_ch=255, training=False, positive=None, new_state=None, capture=None):
     """Forward of make_yolov3_model (yolov3_detect.py:217-311): -> [yolo_82, yolo_94, yolo_106] as NHWC
     tensors (B,S/32,S/32,C), (B,S/16,..), (B,S/8,..).  training=False: the reference's inference graph
     (moving statistics).  training=True (the build's extension): batch statistics in every
@@ -315,6 +315,8 @@ def yolov3_forward(params, state, x_nhwc, nclass_ch=255, training=False, positiv
         y = (z - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + BN_EPS) * params[e['gamma_off']:e['gamma_off'] + cout].view(1, -1, 1, 1) \
             + params[e['beta_off']:e['beta_off'] + cout].view(1, -1, 1, 1)
         i = bn_i[0]; bn_i[0] += 1
+        if capture is not None:      # diagnostics: pre-BN output and the statistics of every BN layer
+            capture[e['name']] = (z.detach().permute(0, 2, 3, 1), mean.detach(), var.detach())
         if positive is None:
             return F.leaky_relu(y, LEAKY)
         pos = positive[i].permute(0, 3, 1, 2)

@@ -222,93 +222,6 @@ def test_conv_slots_then_bn_act(ctx, B, H, cin, cout, k, s, with_skip):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# BatchNorm's backward folded into the operand loads of its consumers (conv.h FvVirtDz)
-FUSED_CASES = [
-    # B, H, cin, cout, k, s   (the conv whose data- and weight-gradient consume dz of its own BN layer)
-    (2, 16, 64, 128, 3, 1),      # 64-wide dgrad tiles, 128x64 wgrad tiles
-    (2, 16, 128, 256, 3, 1),     # 128-wide dgrad tiles, QUAD wgrad
-    (2, 16, 32, 64, 3, 2),       # stride 2: four parity classes
-    (3, 12, 128, 128, 3, 2),     # stride 2, tail rows
-    (2, 13, 256, 128, 1, 1),     # 1x1, odd pixel count
-    (2, 20, 3, 32, 3, 1),        # first layer: gathered weight-gradient (no data-gradient)
-]
-
-
-@pytest.mark.parametrize('B,H,cin,cout,k,s', FUSED_CASES)
-def test_fused_bn_backward_operand_equals_the_separate_pass(ctx, B, H, cin, cout, k, s):
-    """dgrad / wgrad fed (g, z, per-channel vectors) against the SAME kernels fed the dz tensor that
-    fv_bn_bwd_slots wrote (that pass is verified against float64 above): the staged operand values are
-    bit-identical, so the data-gradient -- a deterministic fmaf chain -- must be bit-identical, with and
-    without a residual addend and the fused reduction for the layer below; the weight-gradient (float atomics
-    across K splits) to rounding, and against float64 directly."""
-    from face_vijnana_yolov3_amd import ops
-    Ho = H // s
-    rows = B * Ho * Ho
-    x = _rand((B, H, H, cin), 71); w = _rand((cout, k, k, cin), 72, -0.3, 0.3)
-    z = _rand((B, Ho, Ho, cout), 73, -2.0, 2.0); g = _rand((B, Ho, Ho, cout), 74)
-    scale, shift, mean, invstd = _bn_vectors(cout, 75)
-    zd, gd = z.cuda(), g.cuda()
-    vec = [v.cuda() for v in (scale, shift, mean, invstd)]
-    # the separate pass: reduction into slots, then apply
-    slots = ops.stat_slots(cout, 'cuda')
-    dz, dgamma, dbeta = ops.bn_bwd_slots(ctx, gd, zd, *vec, slots, False)
-    # the fused path's coefficient kernel on the same slots
-    dbeta2, dgamma2, vecs = ops.bn_bwd_coeff(ctx, slots, rows, *vec)
-    assert torch.equal(dbeta, dbeta2) and torch.equal(dgamma, dgamma2)
-    inv = np.float32(1.0 / rows)
-    want_tab = torch.stack([scale, shift, mean, invstd, dbeta.cpu() * inv, dgamma.cpu() * inv]).view(6, cout // 4, 4).permute(1, 0, 2)
-    assert torch.equal(vecs.cpu(), want_tab.contiguous())
-    # weight-gradient
-    ref_dw = ops.conv2d_wgrad(ctx, x.cuda(), dz, cout, k, s)
-    got_dw = ops.conv2d_wgrad_fused(ctx, x.cuda(), gd, zd, vecs, k, s)
-    tol = 1e-5 * ref_dw.abs().max().item()
-    assert (got_dw - ref_dw).abs().max().item() <= tol
-    wt = torch.zeros((cout, k, k, cin), dtype=torch.float64, requires_grad=True)
-    (r64,) = torch.autograd.grad(_ref_conv(x.double(), wt, k, s), wt, dz.cpu().double())
-    wa = torch.zeros((cout, k, k, cin), dtype=torch.float64, requires_grad=True)
-    (b64,) = torch.autograd.grad(_ref_conv(x.double().abs(), wa, k, s), wa, dz.cpu().double().abs())
-    assert ((got_dw.cpu().double() - r64).abs() <= 2e-6 * b64 + 1e-6).all()
-    if cin % 32:
-        return
-    # data-gradient: plain, with addend, and with the reduction for the layer below
-    add = _rand((B, H, H, cin), 76).cuda()
-    assert torch.equal(ops.conv2d_dgrad_fused(ctx, gd, zd, vecs, w.cuda(), (H, H), s), ops.conv2d_dgrad(ctx, dz, w.cuda(), (H, H), s))
-    assert torch.equal(ops.conv2d_dgrad_fused(ctx, gd, zd, vecs, w.cuda(), (H, H), s, addend=add),
-                       ops.conv2d_dgrad(ctx, dz, w.cuda(), (H, H), s, addend=add))
-    z2 = _rand((B, H, H, cin), 77, -2.0, 2.0).cuda()
-    v2 = [v.cuda() for v in _bn_vectors(cin, 78)]
-    s_a, s_b = ops.stat_slots(cin, 'cuda'), ops.stat_slots(cin, 'cuda')
-    dx_a = ops.conv2d_dgrad_fused(ctx, gd, zd, vecs, w.cuda(), (H, H), s, addend=add, bnred=(z2, *v2, s_a))
-    dx_b = ops.conv2d_dgrad_bnred(ctx, dz, w.cuda(), (H, H), s, z2, *v2, s_b, addend=add)
-    assert torch.equal(dx_a, dx_b)
-    # same gy values; the fp32 partial sums over a tile's rows are formed in another order by the 4-wave (fused) and the
-    # 8-wave (plain) kernel: agreement to float32 rounding of the column sums
-    mag = s_b.sum(0).abs().max().item()
-    torch.testing.assert_close(s_a.sum(0), s_b.sum(0), rtol=2e-5, atol=2e-5 * mag)
-
-
-def test_fused_bn_backward_through_the_tail_split(ctx):
-    """The 307-tile shape with scratch lent: K slices of the tail tiles stage the fused operand too."""
-    from face_vijnana_yolov3_amd import ops
-    B, H, cin, cout, k, s = 2, 140, 128, 256, 3, 1
-    rows = B * H * H
-    w = _rand((cout, k, k, cin), 82, -0.1, 0.1)
-    z = _rand((B, H, H, cout), 83, -2.0, 2.0).cuda(); g = _rand((B, H, H, cout), 84).cuda()
-    vec = [v.cuda() for v in _bn_vectors(cout, 85)]
-    slots = ops.stat_slots(cout, 'cuda')
-    dz, _, _ = ops.bn_bwd_slots(ctx, g, z, *vec, slots, False)
-    _, _, vecs = ops.bn_bwd_coeff(ctx, slots, rows, *vec)
-    plain = ops.conv2d_dgrad_fused(ctx, g, z, vecs, w.cuda(), (H, H), s)
-    ctx.set_conv_scratch(torch.empty(64 << 20, dtype=torch.uint8, device='cuda'))
-    try:
-        split = ops.conv2d_dgrad_fused(ctx, g, z, vecs, w.cuda(), (H, H), s)
-        split_ref = ops.conv2d_dgrad(ctx, dz, w.cuda(), (H, H), s)
-    finally:
-        ctx.set_conv_scratch(None)
-    assert torch.equal(plain, ops.conv2d_dgrad(ctx, dz, w.cuda(), (H, H), s))
-    assert torch.equal(split, split_ref) and not torch.equal(split, plain)
-
-
 @pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 96, 128), (3, 8, 32)])
 def test_first_layer_direct_kernel_equals_gather_kernel(ctx, B, H, W):
     """conv0_direct.hip (vector-FMA first layer with an LDS halo tile; taken when W % 32 == 0 and H % 8 == 0) against

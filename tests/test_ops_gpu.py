@@ -345,24 +345,20 @@ def test_fd_loss_and_grad(ctx):
 
 
 @pytest.mark.parametrize('B,H,cin,cout,k,s', [(2, 13, 128, 256, 3, 1), (2, 16, 32, 64, 3, 2), (3, 13, 64, 32, 1, 1), (2, 13, 1024, 6, 3, 1)])
-def test_lds_dma_variant_is_bit_identical(ctx, B, H, cin, cout, k, s):
-    """fv_set_conv_dma: operands staged by buffer_load...lds into a swizzled LDS image; same K order,
-    so the result (incl. zero padding at the borders and the BN partials) is bit-identical."""
+def test_four_and_eight_wave_tiles_are_bit_identical(ctx, B, H, cin, cout, k, s):
+    """fv_set_conv_waves8: 2x4 waves of 64x32 (default) against 2x2 waves of 64x64 -- the same k-ordered fmaf chain per output
+    element, so outputs (incl. zero padding at the borders) and data-gradients are bit-identical."""
     from face_vijnana_yolov3_amd import ops
     x = _rand((B, H, H, cin), 71).cuda(); w = _rand((cout, k, k, cin), 72).cuda()
-    ctx.set_conv_waves8(False)          # the LDS-DMA variant is the 4-wave tiling: compare like with like (BN partial sums included)
+    dy = _rand((B, H // s, H // s, max(32, cout)), 73).cuda()
+    if cout < 32:
+        dy[..., cout:] = 0
+    ref = ops.conv2d_forward(ctx, x, w, stride=s)
+    dg_ref = ops.conv2d_dgrad(ctx, dy, w, (H, H), s)
+    ctx.set_conv_waves8(False)
     try:
-        ref = ops.conv2d_forward(ctx, x, w, stride=s, stats=True)
-        dy = _rand((B, H // s, H // s, max(32, cout)), 73).cuda()
-        if cout < 32:
-            dy[..., cout:] = 0
-        dg_ref = ops.conv2d_dgrad(ctx, dy, w, (H, H), s)
-        ctx.set_conv_dma(True)
-        got = ops.conv2d_forward(ctx, x, w, stride=s, stats=True)
+        got = ops.conv2d_forward(ctx, x, w, stride=s)
         dg = ops.conv2d_dgrad(ctx, dy, w, (H, H), s)
     finally:
-        ctx.set_conv_dma(False); ctx.set_conv_waves8(True)
-    for a, b in zip(ref, got):
-        assert torch.equal(a, b)
-    assert torch.equal(dg, dg_ref)
-    assert torch.equal(ops.conv2d_forward(ctx, x, w, stride=s), ref[0])      # and the default 8-wave form: same outputs
+        ctx.set_conv_waves8(True)
+    assert torch.equal(got, ref) and torch.equal(dg, dg_ref)
