@@ -108,7 +108,7 @@ def _declare(L):
         'fv_yolov3_workspace_bytes': (sz, [i32, i32, i32]),
         'fv_yolov3_forward': (i32, [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, vp, vp]),
         'fv_yolov3_train_workspace_bytes': (sz, [i32, i32, i32]),
-        'fv_yolov3_train_step': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, vp]),
+        'fv_yolov3_train_step': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, vp, BUCKET_FN, vp]),
         'fv_yolov3_train_workspace_tensor': (i32, [i32, i32, i32, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(i64)]),
         'fv_yolo_decode_nms': (i32, [vp, vp, vp, vp, i32, i32, ctypes.POINTER(f32), f32, f64, i32, i32, i32, i32, i32,
                                      vp, vp, vp, vp]),

@@ -30,16 +30,18 @@ __global__ __launch_bounds__(256, 3) void conv0_direct_kernel(const float* __res
                                                            double* __restrict__ slots, int nslot) {
     __shared__ __attribute__((aligned(16))) float halo2[2][HR * HCP];
     __shared__ __attribute__((aligned(16))) float wk[27 * 32];        // [k][n]
-    __shared__ float red[2][64][33];
+    __shared__ double red[2][64][33];   // (only the statistics instantiation keeps it)
     const int tid = threadIdx.x;
     for (int i = tid; i < 27 * 32; i += 256) { const int k = i >> 5, n = i & 31; wk[i] = w32[n * 32 + k]; }
     const int strip = tid >> 2, q = tid & 3;          // strip of 4 pixels, channel group of 8
     const int sr = strip >> 3, sc = (strip & 7) * 4;
     const int tiles_w = W / TW, tiles_h = H / TH;
     const long long ntiles = (long long)B * tiles_h * tiles_w;
-    float ssum[8], ssq[8];
+    // statistics: fp32 over the four pixels of a tile, fp64 across the tiles of this persistent workgroup (43 K values per
+    // channel and workgroup at batch 256: an fp32 chain of that length would cost the mean its last digits)
+    double ssum[8], ssq[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+    for (int c = 0; c < 8; ++c) { ssum[c] = 0.0; ssq[c] = 0.0; }
     float4 sc0 = make_float4(1.f, 1.f, 1.f, 1.f), sc1 = sc0, sh0 = make_float4(0.f, 0.f, 0.f, 0.f), sh1 = sh0;
     if (epi & FV_EPI_AFFINE) {
         if (scale) { sc0 = *reinterpret_cast<const float4*>(scale + 8 * q); sc1 = *reinterpret_cast<const float4*>(scale + 8 * q + 4); }
@@ -119,12 +121,17 @@ __global__ __launch_bounds__(256, 3) void conv0_direct_kernel(const float* __res
             wa = na; wb = nb;
         }
         float* op = out + (((size_t)b * H + h0 + sr) * W + w0 + sc) * 32 + 8 * q;
+        if (epi & FV_EPI_STATS) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float ts = 0.f, tq = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ts += acc[j][c]; tq += acc[j][c] * acc[j][c]; }
+                ssum[c] += (double)ts; ssq[c] += (double)tq;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (epi & FV_EPI_STATS) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) { ssum[c] += acc[j][c]; ssq[c] += acc[j][c] * acc[j][c]; }
-            }
             float4 v0 = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]), v1 = make_float4(acc[j][4], acc[j][5], acc[j][6], acc[j][7]);
             if (epi & FV_EPI_AFFINE) {
                 v0.x = v0.x * sc0.x + sh0.x; v0.y = v0.y * sc0.y + sh0.y; v0.z = v0.z * sc0.z + sh0.z; v0.w = v0.w * sc0.w + sh0.w;
@@ -147,11 +154,11 @@ __global__ __launch_bounds__(256, 3) void conv0_direct_kernel(const float* __res
         __syncthreads();
         if (tid < 64) {
             const int which = tid >> 5, n = tid & 31;
-            float t = 0.f;
+            double t = 0.0;
 #pragma unroll 8
             for (int s = 0; s < 64; ++s) t += red[which][s][n];
             double* sl = slots + (size_t)(blockIdx.x % nslot) * 2 * 32;
-            unsafeAtomicAdd(sl + which * 32 + n, (double)t);
+            unsafeAtomicAdd(sl + which * 32 + n, t);
         }
     }
 }

@@ -167,6 +167,8 @@ bool fv_conv9_fwd_ok(const FvConvArgs& a) {
     if (a.epi != FV_EPI_STATS || !a.stat_slots || a.stat_nslot < 1) return false;
     if ((a.is != 1 && a.is != 2) || a.os != 1 || a.Hout != a.Hl || a.Wout != a.Wl || a.oph[0] || a.opw[0]) return false;
     if (a.Hl * a.is != a.Hin || a.Wl * a.is != a.Win || a.taps[0].n != 9) return false;
+    // masked edge stores use the 32-bit byte offset 0x80000000 as "outside": it must lie beyond the output tensor
+    if ((long long)a.B * a.Hout * a.Wout * a.Nout * 4 >= (1ll << 31)) return false;
     for (int t = 0; t < 9; ++t)
         if (a.taps[0].dh[t] != t / 3 - 1 || a.taps[0].dw[t] != t % 3 - 1 || a.taps[0].wslot[t] != t) return false;
     return true;

@@ -204,6 +204,8 @@ bool fv_dgrad9s2_ok(const FvConvArgs& a) {
     if (a.epi & ~FV_EPI_BNRED) return false;
     if ((a.epi & FV_EPI_BNRED) && (!a.bn_z || !a.bn_slots || a.bn_nslot < 1)) return false;
     if (a.is != 1 || a.os != 2 || a.Hl != a.Hin || a.Wl != a.Win || a.Hout != 2 * a.Hin || a.Wout != 2 * a.Win) return false;
+    // masked dx stores and z loads use the 32-bit byte offset 0x80000000 as "outside": it must lie beyond the output tensor
+    if ((long long)a.B * a.Hout * a.Wout * a.Nout * 4 >= (1ll << 31)) return false;
     // the class table fv_op_conv_dgrad builds for a 3x3 stride-2 layer: class c = 3 - (ph * 2 + pw)
     static const int n_exp[4] = {4, 2, 2, 1};
     for (int c = 0; c < 4; ++c) {

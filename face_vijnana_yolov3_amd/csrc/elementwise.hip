@@ -542,23 +542,34 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         out[i] = v;
     }
 }
-// the same on float4 pieces (n, stride and C multiples of 4; every pointer 16-byte aligned)
+// the same on float4 pieces (n, stride and C multiples of 4; every pointer 16-byte aligned).  One piece per thread, the slabs
+// loaded SIXTEEN at a time (all of a <= 16-way split in one round trip; the sum order stays slab order): the batch-1 detect
+// path is one dependent chain of ~100 launches and this kernel is memory LATENCY, not bandwidth.
 __global__ __launch_bounds__(256) void splitk_finish4_kernel(const float4* __restrict__ slabs, int ksplit, long long stride4,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float4* __restrict__ skip, float4* __restrict__ out, long long n4,
                                                              int C, float leaky, int do_leaky) {
     const int c4n = C >> 2;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (skip) sk = skip[i];                        // in flight with the first round of slabs
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         int k = 0;
-        for (; k + 8 <= ksplit; k += 8) {
-            float4 t[8];
+        for (; k + 16 <= ksplit; k += 16) {
+            float4 t[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = slabs[(k + j) * stride4 + i];
+            for (int j = 0; j < 16; ++j) t[j] = slabs[(k + j) * stride4 + i];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
+            for (int j = 0; j < 16; ++j) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
         }
-        for (; k < ksplit; ++k) { const float4 t = slabs[k * stride4 + i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        {   // the remaining < 16 slabs, again in one round (out-of-range slots re-read the last slab and are not added)
+            float4 t[16];
+            const int rem = ksplit - k;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t[j] = slabs[(k + (j < rem ? j : (rem > 0 ? rem - 1 : -k))) * stride4 + i];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (j < rem) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
+        }
         const int c = (int)(i % c4n) << 2;
         if (scale) { const float4 s = *reinterpret_cast<const float4*>(scale + c); v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w; }
         if (shift) { const float4 s = *reinterpret_cast<const float4*>(shift + c); v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
@@ -566,7 +577,7 @@ __global__ __launch_bounds__(256) void splitk_finish4_kernel(const float4* __res
             v.x = v.x > 0.f ? v.x : v.x * leaky; v.y = v.y > 0.f ? v.y : v.y * leaky;
             v.z = v.z > 0.f ? v.z : v.z * leaky; v.w = v.w > 0.f ? v.w : v.w * leaky;
         }
-        if (skip) { const float4 s = skip[i]; v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+        if (skip) { v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w; }
         out[i] = v;
     }
 }

@@ -294,6 +294,8 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
     Plan p = make_plan(workspace, batch, image_size, true);
     if (p.bytes > workspace_bytes) return fv_fail(ctx, FV_ERR_WORKSPACE, "train_step: workspace %zu < %zu bytes", workspace_bytes, p.bytes);
     TailLend lend(ctx, p);
+    // fv_set_bn_zero_debias_step applies to ONE training step: later per-operator BN calls on this context use their own momentum
+    struct EmaReset { fv_ctx* c; ~EmaReset() { c->bn_ema_step = 0; } } ema_reset{ctx};
     const Net& N = net();
     const int nb = p.nl - 1;
     const int S = image_size;

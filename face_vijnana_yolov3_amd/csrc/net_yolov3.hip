@@ -338,7 +338,7 @@ int fv_yolov3_train_workspace_tensor(int batch, int image_size, int out_channels
 
 int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float* x, const float* yt13, const float* yt26,
                          const float* yt52, int batch, int image_size, int out_channels, void* workspace, size_t workspace_bytes,
-                         float* grads, float* loss) {
+                         float* grads, float* loss, fv_bucket_fn on_bucket, void* user) {
     if (!ctx) return FV_ERR_INVALID;
     FV_REQUIRE(ctx, params && bn_state && x && yt13 && yt26 && yt52 && workspace && grads && loss, "yolov3_train_step: NULL buffer");
     FV_REQUIRE(ctx, batch >= 1 && image_size >= 32 && image_size % 32 == 0 && out_channels >= 18 && out_channels % 3 == 0,
@@ -352,6 +352,7 @@ int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, cons
     float* const prev_tail = ctx->tail_slab; const long long prev_tail_floats = ctx->tail_slab_floats;
     struct Restore { fv_ctx* c; float* s; long long n; ~Restore() { c->tail_slab = s; c->tail_slab_floats = n; } } restore{ctx, prev_tail, prev_tail_floats};
     ctx->tail_slab = ctx->tail_split ? p.tail : nullptr; ctx->tail_slab_floats = ctx->tail_split ? (long long)p.tail_floats : 0;
+    struct EmaReset { fv_ctx* c; ~EmaReset() { c->bn_ema_step = 0; } } ema_reset{ctx};   // the zero-debias step applies to this call only
 
     FV_HIP(ctx, hipMemsetAsync(grads, 0, (size_t)N.nparam * sizeof(float), ctx->stream));
     FV_HIP(ctx, hipMemsetAsync(p.slots[0], 0, p.slots_bytes, ctx->stream));
@@ -436,22 +437,34 @@ int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, cons
     const bool ov = ctx->overlap && ctx->side;
     hipStream_t main_stream = ctx->stream;
     float* const DZs[2] = {p.DZ, p.DZ2};
-    bool pend[2] = {false, false};
+    // A layer's gradient range [w_off, + kernel + (gamma, beta | bias)) is complete once its weight-gradient has finished: it is
+    // handed to the bucket callback when ev_wg[slot] has been waited for (the slots alternate strictly, so ranges are reported
+    // in issue order = reverse execution order = descending offsets, the protocol of fv_train_step).
+    struct Pending { bool on; int64_t off, cnt; } pend[2] = {{false, 0, 0}, {false, 0, 0}};
     int slot = 0;
     auto join = [&](int s) -> int {
-        if (pend[s]) { FV_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_wg[s], 0)); pend[s] = false; }
+        if (!pend[s].on) return FV_OK;
+        FV_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_wg[s], 0));
+        if (on_bucket) on_bucket(user, pend[s].off, pend[s].cnt);
+        pend[s].on = false;
         return FV_OK;
     };
-    auto wgrad = [&](int s, const float* xin, const float* dyv, int H, int cin, int cout, int ndy, int ksize, int stride, float* dw) -> int {
-        if (!ov) return fv_op_conv_wgrad(ctx, xin, dyv, B, H, H, cin, cout, ndy, ksize, stride, dw);
+    auto wgrad = [&](int s, int l, const float* xin, const float* dyv, int H, int ndy, float* dw) -> int {
+        const auto& d = N.L[l].d;
+        const int64_t cnt = (int64_t)d.cout * d.ksize * d.ksize * d.cin + (d.has_bn ? 2 : 1) * d.cout;
+        if (!ov) {
+            if (int rc = fv_op_conv_wgrad(ctx, xin, dyv, B, H, H, d.cin, d.cout, ndy, d.ksize, d.stride, dw)) return rc;
+            if (on_bucket) on_bucket(user, d.w_off, cnt);
+            return FV_OK;
+        }
         FV_HIP(ctx, hipEventRecord(ctx->ev_dz[s], main_stream));
         FV_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_dz[s], 0));
         ctx->stream = ctx->side;
-        const int rc = fv_op_conv_wgrad(ctx, xin, dyv, B, H, H, cin, cout, ndy, ksize, stride, dw);
+        const int rc = fv_op_conv_wgrad(ctx, xin, dyv, B, H, H, d.cin, d.cout, ndy, d.ksize, d.stride, dw);
         ctx->stream = main_stream;
         if (rc) return rc;
         FV_HIP(ctx, hipEventRecord(ctx->ev_wg[s], ctx->side));
-        pend[s] = true;
+        pend[s] = Pending{true, d.w_off, cnt};
         return FV_OK;
     };
     // detection conv: dy (padded) -> dW, and g of its input layer `lin` (with that layer's d-beta/d-gamma reduction)
@@ -459,7 +472,7 @@ int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, cons
         const auto& d = N.L[l].d;
         const int H = S / d.in_div;
         if (int rc = join(slot)) return rc;
-        if (int rc = wgrad(slot, p.a[lin], p.dy[sidx], H, d.cin, d.cout, p.cpad, d.ksize, 1, grads + d.w_off)) return rc;
+        if (int rc = wgrad(slot, l, p.a[lin], p.dy[sidx], H, p.cpad, grads + d.w_off)) return rc;
         slot ^= 1;
         return fv_op_conv_dgrad(ctx, p.dy[sidx], p.wt[l], B, H, H, d.cin, p.cpad, d.ksize, 1, nullptr, g_out, bnred(lin));
     };
@@ -473,7 +486,7 @@ int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, cons
         float* dz = DZs[slot];
         if (int rc = fv_ew_bn_bwd(ctx, g, p.z[l], p.scale[l], p.shift[l], p.mean[l], p.invstd[l], rows, d.cout, LEAKY, nullptr, nullptr,
                                   grads + d.beta_off, grads + d.gamma_off, dz, p.bslots[l], fv_ew_bn_stat_slots(d.cout), reduced)) return rc;
-        if (int rc = wgrad(slot, xin, dz, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off)) return rc;
+        if (int rc = wgrad(slot, l, xin, dz, H, d.cout, grads + d.w_off)) return rc;
         slot ^= 1;
         if (!g_out) return FV_OK;
         return fv_op_conv_dgrad(ctx, dz, p.wt[l], B, H, H, d.cin, d.cout, d.ksize, d.stride, addend, g_out, bnred(lred));
@@ -519,8 +532,8 @@ int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, cons
             if (d.role == 1) ires = -1;
         }
     }
-    if (int rc = join(0)) return rc;
-    return join(1);
+    if (int rc = join(slot)) return rc;          // `slot` now names the older of the two outstanding weight-gradients
+    return join(slot ^ 1);
 }
 
 }  // extern "C"

@@ -55,6 +55,61 @@ def encode_gt(faces, h, w, image_size=416, grid=13, channels=6):
     return gt
 
 
+# ----------------------------------------------------------------------------- three-scale targets
+YOLO_ANCHORS = [[116, 90, 156, 198, 373, 326], [30, 61, 62, 45, 59, 119], [10, 13, 16, 30, 33, 23]]   # yolov3_detect.py:560
+# The reference's decode_netout (yolov3_detect.py:354-362) SKIPS (116,90), (373,326), (62,45), (10,13), (33,23): only these
+# (scale, anchor) pairs ever reach its box list, so they are the ones a face may be assigned to by default.
+YOLO_ANCHORS_DECODED = ((0, 1), (1, 0), (1, 2), (2, 1))
+
+
+def encode_gt_three_scale(faces, h, w, image_size=416, nclass=1, anchors=YOLO_ANCHORS, anchor_keep=YOLO_ANCHORS_DECODED):
+    """Ground truth of one image for the three-scale head: [t13, t26, t52], t_s of shape (g_s, g_s, 3*(5+nclass)) float64 with
+    g_s = image_size/32 * 2^s, laid out [cell][anchor][tx, ty, tw, th, objectness, classes...] like the network output.
+
+    The single-scale encoder (face_detection.py:150-202) generalised: the same skip rule (all of X, Y, W, H > 0), the same
+    integer letterbox arithmetic for the corners and the centre (`int()` truncation, `//2`), cell = centre // cell_size and
+    offset = remainder / cell_size per scale.  New here (the reference never trains this head): the face goes to the ONE
+    (scale, anchor) whose anchor box has the best IoU with the face box (sizes only, network pixels; ties -> the first in
+    `anchor_keep` order) among the anchors the reference's decode keeps, and the box is stored in the parametrisation that
+    decode_netout (yolov3_detect.py:335-387) inverts: sigma(tx) = offset, anchor_w * exp(tw) = box width in network pixels.
+    Offsets are clamped to [0.5/cell, 1 - 0.5/cell] (logit of 0 is -inf; half a pixel is below the decode's int() grain).
+    Objectness 1 and class 0 = 1 at the assigned slot; later rows overwrite earlier ones in the same slot."""
+    S = int(image_size)
+    C = 5 + nclass
+    out = [np.zeros((S // 32 << s, S // 32 << s, 3 * C), np.float64) for s in range(3)]
+    _, _, pad_t, _, pad_l, _ = letterbox_geometry(h, w, S)
+    m = w if w >= h else h
+    ox, oy = (0, pad_t) if w >= h else (pad_l, 0)
+    for fx, fy, fw, fh in np.asarray(faces, dtype=np.float64).reshape(-1, 4):
+        if not (fx > 0 and fy > 0 and fw > 0 and fh > 0):
+            continue
+        x1, y1 = int(fx), int(fy)
+        x2, y2 = x1 + int(fw) - 1, y1 + int(fh) - 1
+        x1p, x2p = int(x1 / m * S) + ox, int(x2 / m * S) + ox
+        y1p, y2p = int(y1 / m * S) + oy, int(y2 / m * S) + oy
+        xc, yc = (x1p + x2p) // 2, (y1p + y2p) // 2
+        bw, bh = (x2 - x1 + 1) / m * S, (y2 - y1 + 1) / m * S          # the single-scale targets bw, bh times the network size
+        best, best_iou = None, -1.0
+        for (s, b) in anchor_keep:
+            aw, ah = anchors[s][2 * b], anchors[s][2 * b + 1]
+            inter = min(bw, aw) * min(bh, ah)
+            iou = inter / (bw * bh + aw * ah - inter)
+            if iou > best_iou:
+                best, best_iou = (s, b), iou
+        s, b = best
+        g = S // 32 << s
+        cell = S // g
+        cx, cy = xc // cell, yc // cell
+        lo, hi = 0.5 / cell, 1.0 - 0.5 / cell
+        px = min(max((xc - cx * cell) / cell, lo), hi); py = min(max((yc - cy * cell) / cell, lo), hi)
+        t = np.zeros(C, np.float64)
+        t[0] = np.log(px / (1.0 - px)); t[1] = np.log(py / (1.0 - py))
+        t[2] = np.log(bw / anchors[s][2 * b]); t[3] = np.log(bh / anchors[s][2 * b + 1])
+        t[4] = 1.0; t[5] = 1.0
+        out[s][cy, cx, b * C:(b + 1) * C] = t
+    return out
+
+
 # ----------------------------------------------------------------------------- bicubic letterbox
 def _cubic_weights(t, a=-0.75):
     t = np.asarray(t, np.float64)
@@ -110,6 +165,15 @@ class TrainingSequence(object):
         self.image_size = nn_arch['image_size']
         self.grid = CELL_SIZE if CELL_SIZE else self.image_size // 32
         self.loader = loader or _pil_loader
+        # nn_arch['head'] == 'three_scale' (the build's extension): three target tensors per image
+        self.three_scale = nn_arch.get('head', 'single') == 'three_scale'
+        self.nclass = int(nn_arch.get('num_classes', 1))
+
+    def encode(self, rows, h, w):
+        """GT of one image: (G,G,6) for the reference's single-scale head, [t13, t26, t52] for the three-scale head."""
+        if self.three_scale:
+            return encode_gt_three_scale(rows, h, w, self.image_size, self.nclass)
+        return encode_gt(rows, h, w, self.image_size, self.grid, self.nn_arch['bb_info_c_size'])
 
     def __len__(self):
         return self.hps['step']
@@ -121,8 +185,10 @@ class TrainingSequence(object):
             raw = self.loader(os.path.join(self.raw_data_path, name))
             img, (h, w, *_rest) = letterbox(raw, self.image_size)
             df = self.groups[name]
-            gts.append(encode_gt(df.iloc[:, 3:7].values, h, w, self.image_size, self.grid, self.nn_arch['bb_info_c_size']))
+            gts.append(self.encode(df.iloc[:, 3:7].values, h, w))
             images.append(img)
+        if self.three_scale:
+            return ({'input1': np.asarray(images)}, {'output%d' % s: np.asarray([g[s] for g in gts]) for s in range(3)})
         return ({'input1': np.asarray(images)}, {'output': np.asarray(gts)})
 
     def get_raw(self, index):
@@ -133,9 +199,10 @@ class TrainingSequence(object):
         for name in names:
             raw = self.loader(os.path.join(self.raw_data_path, name))
             df = self.groups[name]
-            gts.append(encode_gt(df.iloc[:, 3:7].values, raw.shape[0], raw.shape[1], self.image_size, self.grid,
-                                 self.nn_arch['bb_info_c_size']))
+            gts.append(self.encode(df.iloc[:, 3:7].values, raw.shape[0], raw.shape[1]))
             raws.append(raw)
+        if self.three_scale:
+            return raws, [np.asarray([g[s] for g in gts], np.float32) for s in range(3)]
         return raws, np.asarray(gts, np.float32)
 
 

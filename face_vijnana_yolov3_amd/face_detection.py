@@ -10,6 +10,12 @@ ratios.csv, the model files).  Differences, all documented in DESIGN.md:
   * multi_gpu=True means one process per GPU (torchrun) with RCCL all-reduce instead of
     keras.utils.multi_gpu_model towers; launched as a single process it trains on one GPU
   * evaluate() tolerates images without ground-truth rows and a missing arial.ttf
+  * evaluate()/test() read ahead and run the network on batches of hps['eval_batch_size'] images (default 16; the
+    reference's loop is batch 1, fd.py:632-883) -- same rows in the same order
+  * nn_arch['head'] = 'three_scale' (default 'single' = the reference's 13x13x6 head) selects the full three-scale YOLOv3
+    graph (yolov3_detect.py:217-311) with nn_arch['num_classes'] (default 1) classes: trained with the build's
+    objectness / box / class loss on targets from data.encode_gt_three_scale, detected through the reference's
+    decode_netout / correct_yolo_boxes / do_nms chain (fv_yolo_decode_nms)
 """
 import glob
 import json
@@ -57,12 +63,22 @@ class FaceDetector(object):
         self.world = int(os.environ.get('WORLD_SIZE', 1)) if conf.get('multi_gpu') else 1
         if device is None:
             device = int(os.environ.get('LOCAL_RANK', 0))
-        self.model = Engine(device)
+        self.three_scale = self.nn_arch.get('head', 'single') == 'three_scale'
+        if self.nn_arch.get('head', 'single') not in ('single', 'three_scale'):
+            raise ValueError("nn_arch.head must be 'single' or 'three_scale'")
+        if self.three_scale:
+            from .yolov3 import Yolov3
+            self.nclass = int(self.nn_arch.get('num_classes', 1))
+            self.model = Yolov3(device, out_channels=3 * (5 + self.nclass))
+        else:
+            self.model = Engine(device)
         # BN moving statistics as the reference's stack updates them (Keras 2.2.4: zero-debiased); "bn_zero_debias": false in the
         # configuration selects the plain EMA
         self.model.bn_zero_debias = bool(conf.get('bn_zero_debias', True))
         if self.model_loading:
             self.model.load(self.MODEL_PATH)
+        elif self.three_scale:
+            self._load_base_three_scale()
         else:
             self._load_base()
             self._init_head()
@@ -85,6 +101,25 @@ class FaceDetector(object):
                   % (self.BASE_MODEL_PATH, self.DARKNET_WEIGHTS_PATH))
             eng.init_synthetic(seed=7)
 
+    def _load_base_three_scale(self):
+        """Three-scale model: layers 75..105 random-init (BN layers ~ N(0, 2/fan_in), detection convs glorot-uniform, zero
+        bias), the 52 base layers from the cached base file / the Darknet file when present (same flat layout as Engine)."""
+        from . import weights
+        m = self.model
+        m.init_synthetic(seed=7)
+        base = m.layers[:52]
+        n_p = base[-1]['beta_off'] + base[-1]['cout']; n_s = base[-1]['var_off'] + base[-1]['cout']
+        if self.conf.get('yolov3_base_model_load') and os.path.exists(self.BASE_MODEL_PATH):
+            with open(self.BASE_MODEL_PATH, 'rb') as f:
+                d = np.load(f)
+                m.load_base(d['params'][:n_p], d['state'][:n_s])
+        elif os.path.exists(self.DARKNET_WEIGHTS_PATH):
+            p, st = weights.read_darknet_base(self.DARKNET_WEIGHTS_PATH, base, n_p, n_s)
+            m.load_base(p, st)
+        else:
+            print('FaceDetector: neither %s nor %s found; using synthetic base weights'
+                  % (self.BASE_MODEL_PATH, self.DARKNET_WEIGHTS_PATH))
+
     def _init_head(self, seed=None):
         """Keras default for the 'output' Conv2D: glorot_uniform kernel, zero bias (fd.py:348-352)."""
         import torch
@@ -105,6 +140,7 @@ class FaceDetector(object):
         steps = len(seq)
         rng = np.random.default_rng(0)
         feeder = BatchFeeder(seq, self.world, self.rank, int(hp.get('loader_threads', 8)))
+        log_every = max(1, int(hp.get('log_every', 1)))
         for epoch in range(hp['epochs']):
             order = rng.permutation(steps)  # Keras fit_generator shuffles batch order (shuffle=True)
             if self.rank == 0:
@@ -119,8 +155,12 @@ class FaceDetector(object):
                         print('%d/%d - skipped (fewer images than ranks)' % (k + 1, steps))
                     continue
                 loss = train_on_item(self.model, trainer, item, self.image_size, hp)
-                if self.rank == 0 and (DEBUG or k + 1 == steps):
-                    print('%d/%d - loss: %.4f' % (k + 1, steps, float(loss.item())))
+                # Keras prints the loss of the MERGED batch at every step (verbose=1, fd.py:621-627); reading it is a host
+                # sync (and one small all-reduce when world > 1): hps['log_every'] = n prints every n-th step only
+                if ((k + 1) % log_every == 0 and DEBUG) or k + 1 == steps:
+                    lv = trainer.merged_loss(loss, item[2])          # collective: every rank calls it
+                    if self.rank == 0:
+                        print('%d/%d - loss: %.4f' % (k + 1, steps, lv))
         feeder.close()
         if self.rank == 0:
             print('Save the model.')
@@ -130,19 +170,39 @@ class FaceDetector(object):
     # ------------------------------------------------------------------ detect (fd.py:885-949)
     def detect(self, image):
         """image: (1,S,S,3) array in [0,1] -> list[BoundBox], ascending score, at most num_cands."""
+        return self.detect_batch(image)[0]
+
+    def detect_batch(self, images):
+        """(B,S,S,3) array or CUDA tensor -> one list[BoundBox] per image (what evaluate()/test() run per batch)."""
         import torch
-        x = image if torch.is_tensor(image) else np.asarray(image, dtype=np.float32)
+        x = images if torch.is_tensor(images) else np.asarray(images, dtype=np.float32)
+        if self.three_scale:
+            return self._detect_three_scale(x)
         y = self.model.predict_device(x)
         res = decode_nms(self.model.ctx, y, self.image_size, self.hps['face_conf_th'], self.hps['nms_iou_th'],
                          self.hps['num_cands'])
-        return to_boundboxes(res, 0)
+        # one D2H copy per tensor for the whole batch instead of four per image
+        host = {k: v.cpu() for k, v in res.items()}
+        return [to_boundboxes(host, b) for b in range(y.shape[0])]
 
-    def detect_batch(self, images):
-        """(B,S,S,3) -> list of list[BoundBox] (the batched form evaluate/test could use)."""
-        y = self.model.predict_device(np.asarray(images, dtype=np.float32))
-        res = decode_nms(self.model.ctx, y, self.image_size, self.hps['face_conf_th'], self.hps['nms_iou_th'],
-                         self.hps['num_cands'])
-        return [to_boundboxes(res, b) for b in range(y.shape[0])]
+    def _detect_three_scale(self, x):
+        """Three-scale head: the reference's decode_netout -> correct_yolo_boxes -> do_nms chain (yolov3_detect.py:335-444,
+        one fv_yolo_decode_nms launch pair per image) on the letterboxed image, so boxes come back in network pixels like the
+        single-scale detect(); then detect()'s own tail (fd.py:942-947): score > 0, ascending, at most num_cands."""
+        from .yolov3 import decode_nms as yolo_decode_nms
+        S = self.image_size
+        ys = self.model.predict_device(x)
+        out = []
+        for b in range(ys[0].shape[0]):
+            r = yolo_decode_nms(self.model.ctx, ys[0][b], ys[1][b], ys[2][b], (S, S), (S, S), obj_thresh=self.hps['face_conf_th'],
+                                nms_thresh=self.hps['nms_iou_th'])
+            bx = r['boxes'].cpu().numpy().astype(np.int64); ob = r['objness'].cpu().numpy(); cl = r['classes'].cpu().numpy()
+            boxes = [BoundBox(bx[k, 0], bx[k, 1], bx[k, 2], bx[k, 3], objness=ob[k], classes=list(cl[k])) for k in range(bx.shape[0])]
+            boxes = [bb for bb in boxes if bb.get_score() > 0]
+            scores = np.array([bb.get_score() for bb in boxes], np.float32)
+            order = np.argsort(scores, kind='stable')
+            out.append([boxes[i] for i in order[:self.hps['num_cands']]])
+        return out
 
     # ------------------------------------------------------------------ evaluate / test
     def _project_back(self, boxes, geom):
@@ -171,13 +231,27 @@ class FaceDetector(object):
         names = sorted(glob.glob(os.path.join(test_path, '*.jpg')))
         return shard_files(names, self.world, self.rank) if self.world > 1 else names
 
-    def _run_file(self, file_name):
-        raw = data._pil_loader(file_name)
-        # letterbox on the device (fv_letterbox); data.letterbox is the CPU form of the same formula
-        img, geom = letterbox_device(self.model.ctx, raw, self.image_size)
-        boxes = self.detect(img[None])
-        self._project_back(boxes, geom)
-        return raw, boxes
+    def _detect_files(self, files):
+        """Yield (file_name, raw image, boxes in image coordinates) in file order.  The reference's evaluate()/test() loops
+        (fd.py:632-883) decode, letterbox and predict one image at a time; here a thread pool decodes batch k+1 (PIL releases
+        the GIL) while batch k is letterboxed in one launch (fv_letterbox_batch) and runs ONE forward + ONE decode/NMS launch
+        -- batch 1 is the slowest operating point of the network (1.3 ms/img against 0.4 at batch 16+)."""
+        bs = max(1, int(self.hps.get('eval_batch_size', 16)))
+        chunks = [files[i:i + bs] for i in range(0, len(files), bs)]
+        if not chunks:
+            return
+        threads = max(1, min(bs, int(self.hps.get('loader_threads', 8))))
+        with ThreadPoolExecutor(max_workers=threads) as pool, ThreadPoolExecutor(max_workers=1) as one:
+            load = lambda chunk: list(pool.map(data._pil_loader, chunk))
+            pending = one.submit(load, chunks[0])
+            for k, chunk in enumerate(chunks):
+                raws = pending.result()
+                if k + 1 < len(chunks):
+                    pending = one.submit(load, chunks[k + 1])
+                x, geoms = letterbox_batch_device(self.model.ctx, raws, self.image_size, self.model.dev)
+                for name, raw, boxes, geom in zip(chunk, raws, self.detect_batch(x), geoms):
+                    self._project_back(boxes, geom)
+                    yield name, raw, boxes
 
     def evaluate(self):
         import pandas as pd
@@ -193,10 +267,9 @@ class FaceDetector(object):
         files = self._files(test_path)
         ratios = []
         with open(part_path(out_path, self.world, self.rank), 'w') as f:
-            for n, file_name in enumerate(files):
+            for n, (file_name, raw, boxes) in enumerate(self._detect_files(files)):
                 if DEBUG:
                     print(n + 1, '/', len(files), file_name)
-                raw, boxes = self._run_file(file_name)
                 self._write_rows(f, file_name, boxes)
                 if len(boxes) == 0:
                     continue
@@ -237,10 +310,9 @@ class FaceDetector(object):
         if self.world > 1:
             ensure_process_group(self.model.dev)
         with open(part_path(out_path, self.world, self.rank), 'w') as f:
-            for n, file_name in enumerate(files):
+            for n, (file_name, _raw, boxes) in enumerate(self._detect_files(files)):
                 if DEBUG:
                     print(n + 1, '/', len(files), file_name)
-                _raw, boxes = self._run_file(file_name)
                 self._write_rows(f, file_name, boxes)
         merge_rank_files(out_path, self.world, self.rank)
 
@@ -320,10 +392,14 @@ class BatchFeeder(object):
             raws = list(self.pool.map(lambda nm: seq.loader(os.path.join(seq.raw_data_path, nm)), mine))
             packed = pack_images(raws, pin=pin)
             shapes = [(r.shape[0], r.shape[1]) for r in raws]
-        y = np.asarray([data.encode_gt(seq.groups[nm].iloc[:, 3:7].values, h, w, seq.image_size, seq.grid,
-                                       seq.nn_arch['bb_info_c_size']) for nm, (h, w) in zip(mine, shapes)], np.float32)
-        yt = torch.from_numpy(y)
-        return packed, (yt.pin_memory() if pin else yt), weight, (self, slot)
+        enc = [seq.encode(seq.groups[nm].iloc[:, 3:7].values, h, w) for nm, (h, w) in zip(mine, shapes)]
+        if getattr(seq, 'three_scale', False):      # [t13, t26, t52] per image -> three stacked tensors
+            yt = tuple(torch.from_numpy(np.asarray([e[s] for e in enc], np.float32)) for s in range(3))
+            yt = tuple(t.pin_memory() for t in yt) if pin else yt
+        else:
+            yt = torch.from_numpy(np.asarray(enc, np.float32))
+            yt = yt.pin_memory() if pin else yt
+        return packed, yt, weight, (self, slot)
 
     def prefetch(self, index):
         self.pending = self.one.submit(self.load, index)
@@ -342,8 +418,8 @@ def train_on_item(engine, trainer, item, image_size, hp):
     x, _ = letterbox_batch_device(engine.ctx, None, image_size, engine.dev, packed=packed)
     if slot is not None:
         feeder.copied(slot)
-    return trainer.train_on_batch(x, y.to(engine.dev, non_blocking=True), hp['lr'], hp['beta_1'], hp['beta_2'],
-                                  hp.get('decay', 0.0), weight=weight)
+    yd = [t.to(engine.dev, non_blocking=True) for t in y] if isinstance(y, (tuple, list)) else y.to(engine.dev, non_blocking=True)
+    return trainer.train_on_batch(x, yd, hp['lr'], hp['beta_1'], hp['beta_2'], hp.get('decay', 0.0), weight=weight)
 
 
 def _font():

@@ -140,6 +140,15 @@ class DataParallelTrainer(object):
         eng.adam_step(lr, beta_1, beta_2, decay)
         return loss
 
+    def merged_loss(self, loss, weight=None):
+        """Loss of the merged batch, sum_r n_r/N * loss_r -- what Keras prints for a multi_gpu_model step (one loss over the
+        concatenated tower outputs, fd.py:366-371).  Host sync; a collective when a group exists (every rank must call it)."""
+        if not self.collective or self.world == 1:
+            return float(loss.item())
+        t = loss.detach().double().reshape(1) * (float(weight) if weight is not None else 1.0 / self.world)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
     def barrier(self):
         if self.collective:
             dist.barrier()

@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import Context, LayerDesc, lib, ptr
+from ._lib import BUCKET_FN, Context, LayerDesc, lib, ptr
 
 COCO_ANCHORS = [[116, 90, 156, 198, 373, 326], [30, 61, 62, 45, 59, 119], [10, 13, 16, 30, 33, 23]]  # yd.py:560
 
@@ -109,21 +109,40 @@ class Yolov3(object):
             self._tws = {key: torch.empty(n, dtype=torch.uint8, device=self.dev)}
         return self._tws[key]
 
-    def forward_backward(self, x, targets):
-        """x (B,S,S,3); targets: three tensors shaped like the outputs, (B,g,g,3*(5+classes)).  Gradients land in
-        self.grads; returns the loss (1-element CUDA tensor)."""
+    def ensure_optimizer(self):
         if self.grads is None:
             self.grads = torch.zeros_like(self.params); self.m = torch.zeros_like(self.params); self.v = torch.zeros_like(self.params)
+
+    def forward_backward(self, x, targets, on_bucket=None):
+        """x (B,S,S,3); targets: three tensors shaped like the outputs, (B,g,g,3*(5+classes)).  Gradients land in
+        self.grads; returns the loss (1-element CUDA tensor).  on_bucket(offset, count): called as gradient ranges complete
+        (descending offsets), the protocol of Engine.forward_backward -- parallel.DataParallelTrainer drives either."""
+        self.ensure_optimizer()
         x = torch.as_tensor(x).to(device=self.dev, dtype=torch.float32).contiguous()
         B, S = x.shape[0], x.shape[1]
         t = [torch.as_tensor(y).to(device=self.dev, dtype=torch.float32).contiguous() for y in targets]
         for y, dv in zip(t, (32, 16, 8)):
             assert y.numel() == B * (S // dv) ** 2 * self.out_channels, tuple(y.shape)
         ws = self._train_ws(B, S)
+        cb_error = []
+        if on_bucket is not None:
+            def _cb(user, off, cnt):      # a ctypes callback swallows exceptions: keep the first, re-raise after the call
+                if cb_error:
+                    return
+                try:
+                    on_bucket(int(off), int(cnt))
+                except BaseException as e:   # noqa: B902
+                    cb_error.append(e)
+            cb = BUCKET_FN(_cb)
+        else:
+            cb = ctypes.cast(None, BUCKET_FN)
+        self._bucket_cb = cb
         self.ctx.set_bn_zero_debias_step(self.bn_updates + 1 if self.bn_zero_debias else 0)
         rc = lib().fv_yolov3_train_step(self.ctx.handle, ptr(self.params), ptr(self.state), ptr(x), ptr(t[0]), ptr(t[1]), ptr(t[2]), B, S,
-                                        self.out_channels, ptr(ws), ws.numel(), ptr(self.grads), ptr(self._loss))
+                                        self.out_channels, ptr(ws), ws.numel(), ptr(self.grads), ptr(self._loss), cb, None)
         self.ctx.check(rc, 'fv_yolov3_train_step')
+        if cb_error:
+            raise cb_error[0]
         self.bn_updates += 1
         return self._loss
 
@@ -137,6 +156,33 @@ class Yolov3(object):
         loss = self.forward_backward(x, targets)
         self.adam_step(lr, beta_1, beta_2, decay)
         return loss
+
+    def save(self, path):
+        """Weights + BN moving statistics + Adam state, the npz layout of Engine.save (plus out_channels)."""
+        d = dict(params=self.params.cpu().numpy(), state=self.state.cpu().numpy(), iterations=np.int64(self.iterations),
+                 out_channels=np.int64(self.out_channels))
+        if self.m is not None:
+            d['m'] = self.m.cpu().numpy(); d['v'] = self.v.cpu().numpy()
+        with open(path, 'wb') as f:
+            np.savez(f, **d)
+
+    def load(self, path):
+        with open(path, 'rb') as f:
+            d = np.load(f)
+            if 'out_channels' in d and int(d['out_channels']) != self.out_channels:
+                raise ValueError('%s holds a model with %d output channels, this one has %d' % (path, int(d['out_channels']), self.out_channels))
+            self.set_params(torch.from_numpy(d['params']), torch.from_numpy(d['state']))
+            self.iterations = int(d['iterations'])
+            if 'm' in d:
+                self.ensure_optimizer()
+                self.m.copy_(torch.from_numpy(d['m'])); self.v.copy_(torch.from_numpy(d['v']))
+
+    def load_base(self, params, state):
+        """Copy the 52 base layers (the FaceDetector base: same flat layout at the same offsets) from an Engine-shaped pair."""
+        nb = self.layers[51]
+        n_p = nb['beta_off'] + nb['cout']; n_s = nb['var_off'] + nb['cout']
+        self.params[:n_p].copy_(torch.as_tensor(params, dtype=torch.float32).reshape(-1)[:n_p].to(self.dev))
+        self.state[:n_s].copy_(torch.as_tensor(state, dtype=torch.float32).reshape(-1)[:n_s].to(self.dev))
 
     def leaky_slopes_taken(self, B, S):
         """Per BN layer (fv_yolov3_layer order, detection convs skipped): bool tensor, True where the last train step

@@ -75,8 +75,9 @@ int fv_set_conv_halo(fv_ctx* ctx, int on);
  * TF 1.x `assign_moving_average(..., zero_debias=True)`).  step = 0 (default): plain EMA, moving <- m moving + (1 - m) batch.
  * step = t >= 1: the t-th zero-debiased update since the model was built, moving_t = b_t / (1 - m^t) with the zero-initialised
  * b_t = m b_{t-1} + (1 - m) batch_t -- the first update REPLACES the stored value (so loaded Darknet statistics are forgotten
- * at the first training step, as in the reference's stack).  The caller advances t once per training step.  Parity unpinned
- * (neither Keras nor TF is importable here). */
+ * at the first training step, as in the reference's stack).  The setting is consumed by the NEXT fv_train_step /
+ * fv_yolov3_train_step (which resets it to 0 when it returns) or by the per-operator fv_bn_finalize / fv_bn_act_slots calls that
+ * follow; the caller sets t before every training step.  Parity unpinned (neither Keras nor TF is importable here). */
 int fv_set_bn_zero_debias_step(fv_ctx* ctx, long long step);
 /* First layer (3 -> 32 channels, K = 27, HBM-bound): 1 (default) a direct vector-FMA kernel with an LDS halo tile
  * whenever W % 32 == 0 and H % 8 == 0; 0 the matrix-core gather kernel.  Bit-identical outputs (same fmaf chain). */
@@ -293,11 +294,14 @@ int fv_yolov3_forward(fv_ctx* ctx, const float* params, const float* bn_state, c
  * three scales of the mean over (cell, anchor) of
  *     ( bce(t4, y4) + mean_{k<4} |t_k - y_k| + mean_c bce(t_{5+c}, y_{5+c}) ) / 3
  * -- the reference's fd_loss (fd.py:59-64) generalised to 3 anchors and `classes` classes, with the
- * cross-entropies on logits: bce(t, y) = max(t,0) - t*y + log1p(exp(-|t|)).  Follow with fv_adam_step. */
+ * cross-entropies on logits: bce(t, y) = max(t,0) - t*y + log1p(exp(-|t|)).  Follow with fv_adam_step.
+ * on_bucket (may be NULL): as in fv_train_step -- called on the host as the gradient range of a layer completes, in reverse
+ * execution order = descending offsets, contiguous, covering every parameter once (data-parallel overlap of the all-reduce). */
 size_t fv_yolov3_train_workspace_bytes(int batch, int image_size, int out_channels);
 int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float* x, const float* yt13,
                          const float* yt26, const float* yt52, int batch, int image_size, int out_channels,
-                         void* workspace, size_t workspace_bytes, float* grads, float* loss);
+                         void* workspace, size_t workspace_bytes, float* grads, float* loss, fv_bucket_fn on_bucket,
+                         void* user);
 /* as fv_train_workspace_tensor, for the workspace of fv_yolov3_train_step (BN layers of fv_yolov3_layer) */
 int fv_yolov3_train_workspace_tensor(int batch, int image_size, int out_channels, int layer, int which,
                                      size_t* offset_bytes, int64_t* count);

@@ -97,6 +97,51 @@ def gt_encode_image(rows, h, w, image_size=416, grid=13, channels=6):
     return gt
 
 
+def gt_encode_three_scale(rows, h, w, image_size=416, nclass=1, allowed=((0, 1), (1, 0), (1, 2), (2, 1))):
+    """The build's three-scale target encoder restated (face_vijnana_yolov3_amd/data.py:encode_gt_three_scale; the reference
+    trains no three-scale head, so there is nothing of the reference's to pin this to except its decode: the round trip
+    decode_netout(encode(box)) below, yolov3_detect.py:335-404).  Box / centre integers as face_detection.py:150-177; anchors
+    yolov3_detect.py:560; `allowed` = the (scale, anchor) pairs the reference's decode does not skip (yolov3_detect.py:354-362)."""
+    anchors = ((116, 90, 156, 198, 373, 326), (30, 61, 62, 45, 59, 119), (10, 13, 16, 30, 33, 23))
+    S = image_size
+    nch = 5 + nclass
+    grids = [S // 32, S // 16, S // 8]
+    out = [np.zeros((g, g, 3, nch), np.float64) for g in grids]
+    _, _, pad_t, _, pad_l, _ = letterbox_geometry(h, w, S)
+    for fx, fy, fw, fh in rows:
+        if min(fx, fy, fw, fh) <= 0:
+            continue
+        x1 = int(fx); y1 = int(fy)
+        x2 = x1 + int(fw) - 1; y2 = y1 + int(fh) - 1
+        if w >= h:
+            x1_p = int(x1 / w * S); y1_p = int(y1 / w * S) + pad_t
+            x2_p = int(x2 / w * S); y2_p = int(y2 / w * S) + pad_t
+            bw = (x2 - x1 + 1) / w * S; bh = (y2 - y1 + 1) / w * S
+        else:
+            x1_p = int(x1 / h * S) + pad_l; y1_p = int(y1 / h * S)
+            x2_p = int(x2 / h * S) + pad_l; y2_p = int(y2 / h * S)
+            bw = (x2 - x1 + 1) / h * S; bh = (y2 - y1 + 1) / h * S
+        xc = (x1_p + x2_p) // 2; yc = (y1_p + y2_p) // 2
+        ious = []
+        for (sc, b) in allowed:
+            aw = anchors[sc][2 * b]; ah = anchors[sc][2 * b + 1]
+            i = min(aw, bw) * min(ah, bh)
+            ious.append(i / (aw * ah + bw * bh - i))
+        sc, b = allowed[int(np.argmax(ious))]          # argmax returns the first maximum
+        cell = S // grids[sc]
+        col = xc // cell; row = yc // cell
+        ox = (xc % cell) / cell; oy = (yc % cell) / cell
+        half = 0.5 / cell
+        ox = half if ox < half else (1 - half if ox > 1 - half else ox)
+        oy = half if oy < half else (1 - half if oy > 1 - half else oy)
+        v = out[sc][row, col, b]
+        v[:] = 0.0
+        v[0] = math.log(ox) - math.log1p(-ox); v[1] = math.log(oy) - math.log1p(-oy)
+        v[2] = math.log(bw / anchors[sc][2 * b]); v[3] = math.log(bh / anchors[sc][2 * b + 1])
+        v[4] = 1.0; v[5] = 1.0
+    return [o.reshape(o.shape[0], o.shape[1], 3 * nch) for o in out]
+
+
 def training_batches(file_names, batch_size):
     """face_detection.py:84-90, 103-104, 207: sorted unique file names, fixed consecutive
     slices, short last batch.  Returns list of lists of file names."""

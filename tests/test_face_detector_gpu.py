@@ -115,12 +115,14 @@ def test_main_reads_json_from_cwd(tmp_path, monkeypatch):
     assert os.path.exists(conf['output_file_path'])
 
 
-def test_csv_rows_match_the_reference_test_golden(tmp_path, monkeypatch, golden_dir):
+@pytest.mark.parametrize('eval_batch', [16, 3, 1])
+def test_csv_rows_match_the_reference_test_golden(tmp_path, monkeypatch, golden_dir, eval_batch):
     """a-15: the rows FaceDetector.test() writes -- letterbox geometry, detect(), the back-projection with its
     np.min/np.max clamps (fd.py:841-851), the 60-row cap and the str() formatting (fd.py:866-873) -- against
     tests/golden/test_csv.npz, minted by running the reference's own test() on the same (h, w) shapes with
     the same head output per image (make_golden.py: imread/cv2 are shape-only stand-ins there, here the
-    network is replaced by the golden head the same way).  Text-identical rows, per file."""
+    network is replaced by the golden head the same way).  Text-identical rows, per file -- whatever the batch size
+    evaluate()/test() feed the network with (the reference's loop is batch 1)."""
     import torch
     from face_vijnana_yolov3_amd import data
     from face_vijnana_yolov3_amd.face_detection import FaceDetector
@@ -133,21 +135,26 @@ def test_csv_rows_match_the_reference_test_golden(tmp_path, monkeypatch, golden_
     for f in files:
         open(os.path.join(root, f), 'w').close()
     conf = _conf(root, 'test')
+    conf['hps']['eval_batch_size'] = eval_batch
     fd = FaceDetector(conf)
-    current = []
+    order = sorted(files)              # FaceDetector walks sorted(glob('*.jpg')) in batches of eval_batch_size, reading one batch ahead
+    pos = [0]
 
     def loader(path):
-        current.append(os.path.basename(path))
-        h, w = hw[current[-1]]
+        h, w = hw[os.path.basename(path)]
         return np.zeros((h, w, 3), np.uint8)
 
     def predict_device(x):
-        assert tuple(x.shape) == (1, 416, 416, 3)
-        return torch.from_numpy(g['head'][files.index(current[-1])][None]).cuda()
+        n = int(x.shape[0])
+        assert tuple(x.shape[1:]) == (416, 416, 3) and 1 <= n <= eval_batch
+        names = order[pos[0]:pos[0] + n]
+        pos[0] += n
+        return torch.from_numpy(np.stack([g['head'][files.index(f)] for f in names])).cuda()
 
     monkeypatch.setattr(data, '_pil_loader', loader)
     monkeypatch.setattr(fd.model, 'predict_device', predict_device)
     fd.test()
+    assert pos[0] == len(files)
     text = open(conf['output_file_path']).read().splitlines()
     for k, f in enumerate(files):
         want = str(g['rows'][k]).split('\n') if str(g['rows'][k]) else []
@@ -166,5 +173,6 @@ def test_csv_rows_match_the_reference_test_golden(tmp_path, monkeypatch, golden_
     import pandas as pd
     pd.DataFrame([[0, files[0], 1, 10.0, 10.0, 20.0, 20.0]], columns=data.CSV_COLUMNS).to_csv(os.path.join(root, 'validation.csv'), index=False)
     fd.conf = dict(conf, output_file_path=os.path.join(root, 'solution_eval.csv'))
+    pos[0] = 0
     fd.evaluate()
     assert open(os.path.join(root, 'solution_eval.csv')).read().splitlines() == text

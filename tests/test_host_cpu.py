@@ -100,3 +100,76 @@ def test_cpu_letterbox_matches_oracle_statement():
         raw = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         got, _ = data.letterbox(raw, 64)
         np.testing.assert_allclose(got, host_oracle.letterbox_pixels(raw, 64), rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------ three-scale targets
+def _random_faces(rng, h, w, n):
+    fw = rng.uniform(6, w / 2.5, n); fh = rng.uniform(6, h / 2.5, n)
+    fx = rng.uniform(1, w - fw - 1); fy = rng.uniform(1, h - fh - 1)
+    rows = np.stack([fx, fy, fw, fh], 1)
+    if n > 2:
+        rows[1, 0] = 0.0          # a row the skip rule drops (fd.py:154-156)
+    return rows
+
+
+def test_three_scale_encoder_matches_the_oracle_restatement():
+    from oracle import host_oracle
+    rng = np.random.default_rng(11)
+    for S in (416, 608, 96):
+        for (h, w) in [(480, 640), (640, 480), (500, 500), (301, 1000), (1080, 607)]:
+            rows = _random_faces(rng, h, w, 7)
+            got = data.encode_gt_three_scale(rows, h, w, S)
+            want = host_oracle.gt_encode_three_scale([tuple(r) for r in rows], h, w, S)
+            for s in range(3):
+                assert got[s].shape == (S // 32 << s, S // 32 << s, 18)
+                np.testing.assert_allclose(got[s], want[s], rtol=0, atol=1e-12)
+            assert sum(int((g.reshape(g.shape[0], g.shape[1], 3, 6)[..., 4] == 1).sum()) for g in got) <= 6
+
+
+def test_three_scale_targets_decode_back_to_the_boxes_through_the_reference_decode():
+    """encode -> (targets taken as network outputs, objectness / class logits +-12) -> the oracle restatement of the REFERENCE's
+    decode_netout + correct_yolo_boxes (yolov3_detect.py:335-404, pinned by tests/golden/decode_netout*.npz) must give back
+    every face: centre within the half-pixel clamp, size = the single-scale target's size, corners within 1 px of the truncated
+    expectation -- and only anchors the reference's skip list keeps carry objects."""
+    from oracle import host_oracle
+    rng = np.random.default_rng(12)
+    S = 416
+    anchors = data.YOLO_ANCHORS
+    for (h, w) in [(480, 640), (640, 480), (720, 1280)]:
+        rows = _random_faces(rng, h, w, 5)
+        tg = data.encode_gt_three_scale(rows, h, w, S)
+        boxes = []
+        for s in range(3):
+            out = tg[s].reshape(tg[s].shape[0], tg[s].shape[1], 3, 6).copy()
+            obj = out[..., 4] == 1
+            for (sc, b) in [(0, 0), (0, 2), (1, 1), (2, 0), (2, 2)]:
+                if sc == s:
+                    assert not obj[..., b].any()                      # never assigned to an anchor the decode skips
+            out[..., 4:] = np.where(out[..., 4:] > 0.5, 12.0, -12.0)
+            boxes += host_oracle.decode_netout(out.reshape(tg[s].shape).astype(np.float32), anchors[s], s, 0.5, S, S)
+        host_oracle.correct_yolo_boxes(boxes, S, S, S, S)
+        m = max(h, w)
+        _, _, pad_t, _, pad_l, _ = data.letterbox_geometry(h, w, S)
+        ox, oy = (0, pad_t) if w >= h else (pad_l, 0)
+        want = []
+        for fx, fy, fw, fh in rows:
+            if min(fx, fy, fw, fh) <= 0:
+                continue
+            x1, y1 = int(fx), int(fy); x2, y2 = x1 + int(fw) - 1, y1 + int(fh) - 1
+            xc = (int(x1 / m * S) + ox + int(x2 / m * S) + ox) // 2; yc = (int(y1 / m * S) + oy + int(y2 / m * S) + oy) // 2
+            bw, bh = (x2 - x1 + 1) / m * S, (y2 - y1 + 1) / m * S
+            want.append((xc - bw / 2, yc - bh / 2, xc + bw / 2, yc + bh / 2))
+        assert len(boxes) == len(want)
+        for wb in want:
+            d = [max(abs(b[k] - wb[k]) for k in range(4)) for b in boxes]
+            assert min(d) <= 1.5, (wb, boxes)                         # int() truncation (< 1) + the half-pixel offset clamp
+
+
+def test_training_sequence_three_scale_contract(tmp_path):
+    data.make_synthetic_uccs(str(tmp_path), n_images=3, seed=4)
+    seq = data.TrainingSequence(str(tmp_path), {'batch_size': 2, 'step': 1}, {'image_size': 64, 'bb_info_c_size': 6, 'head': 'three_scale'})
+    x, y = seq[0]
+    assert x['input1'].shape == (2, 64, 64, 3)
+    assert [y['output%d' % s].shape for s in range(3)] == [(2, 2, 2, 18), (2, 4, 4, 18), (2, 8, 8, 18)]
+    raws, gts = seq.get_raw(1)
+    assert len(raws) == 1 and [g.shape for g in gts] == [(1, 2, 2, 18), (1, 4, 4, 18), (1, 8, 8, 18)]

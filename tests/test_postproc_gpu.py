@@ -114,18 +114,22 @@ def test_invalid_arguments_report_errors(ctx):
 
 @pytest.mark.parametrize('h,w,S', [(37, 61, 64), (80, 45, 64), (64, 64, 64), (480, 640, 416), (601, 333, 416), (1080, 1920, 416)])
 def test_device_letterbox_pixels_parity_unpinned(ctx, h, w, S):
-    """fv_letterbox: geometry exact (pinned by the GT-encoder golden); pixels within fp32 rounding of the
-    float64 statement of the same bicubic formula by the same author -- PARITY UNPINNED against
-    cv2.resize(INTER_CUBIC) itself, which is absent from this image."""
+    """fv_letterbox against oracle/host_oracle.letterbox_pixels -- the plain-loop float64 restatement of image/255 ->
+    cv2.resize(INTER_CUBIC) -> copyMakeBorder (face_detection.py:112-147) -- directly: geometry exact (pinned by the GT-encoder
+    golden), pixels within fp32 rounding.  PARITY UNPINNED against cv2.resize itself, which is absent from this image
+    (SURVEY 8c): the oracle is one independent statement of OpenCV's documented bicubic (a = -0.75, half-pixel centres,
+    replicated border), not its output."""
     from face_vijnana_yolov3_amd import data
     from face_vijnana_yolov3_amd.postproc import letterbox_device
+    from oracle import host_oracle
     rng = np.random.default_rng(h * 1000 + w)
     raw = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
     out, geom = letterbox_device(ctx, raw, S)
-    want, wgeom = data.letterbox(raw, S)
-    assert tuple(geom) == tuple(wgeom)
+    want = host_oracle.letterbox_pixels(raw, S)
+    w_p, h_p, pt, pb, pl, pr = host_oracle.letterbox_geometry(h, w, S)
+    assert tuple(geom) == (h, w, pt, pb, pl, pr)
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=3e-6)
-    w_p, h_p, pt, pb, pl, pr = data.letterbox_geometry(h, w, S)
+    np.testing.assert_allclose(data.letterbox(raw, S)[0], want, rtol=0, atol=1e-12)          # the product's CPU form too
     o = out.cpu().numpy()
     assert o[:pt].sum() == 0 and o[S - pb:].sum() == 0 and o[:, :pl].sum() == 0 and o[:, S - pr:].sum() == 0
 

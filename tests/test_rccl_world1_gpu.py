@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
-import os, sys, socket
+import os, sys
 sys.path.insert(0, %(root)r)
 import torch, torch.distributed as dist
 from face_vijnana_yolov3_amd.engine import Engine
@@ -29,9 +29,7 @@ for mode in ('plain', 'rccl'):
     eng.init_synthetic(seed=7)
     eng.iterations = 0; eng.m = eng.v = eng.grads = None
     if mode == 'rccl':
-        with socket.socket() as sk:
-            sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]
-        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%%d' %% port, rank=0, world_size=1, device_id=eng.dev)
+        dist.init_process_group('nccl', store=dist.HashStore(), rank=0, world_size=1, device_id=eng.dev)
     tr = DataParallelTrainer(eng, world_size=1, rank=0, bucket_bytes=8 << 20, force_bucket_path=(mode == 'rccl'))
     assert tr.collective == (mode == 'rccl')
     tr.time_comm = True
