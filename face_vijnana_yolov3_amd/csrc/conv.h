@@ -47,6 +47,7 @@ struct FvConvArgs {
     int tail_f;        // >1: tail split active (set by the launcher): tiles >= tail_full are cut into tail_f K-slices
     int tail_full;
     float* tail_slab;  // [tail tiles * tail_f][128][BN] raw partial tiles
+    int narrow;        // 1: 128x32 tiles whatever Nout (small-M 1x1 layers of the inference path, fv_conv_narrow)
     int ksplit;        // >1: blockIdx.y owns a slice of the K steps and stores its raw partial to out + y*split_stride
     long long split_stride;
     int oph[4], opw[4];
@@ -57,6 +58,9 @@ struct FvConvArgs {
 int fv_conv_mtiles(int M, int Nout);
 // K-split factor the small-M inference path uses for a problem (1 = no split).
 int fv_conv_choose_ksplit(int M, int Nout, int ksteps);
+// Small-M inference: a 1x1 layer (8..16 K steps) whose 128-wide tiling gives fewer than 64 tiles runs on 128x32 tiles WITHOUT a K
+// split -- one launch instead of conv + split-K finish (a kernel costs >= 3.7 us on MI355X however little it does).
+bool fv_conv_narrow(int M, int Nout, int ksteps);
 // Tail split plan for a launch (M rows, Nout channels, ksteps K steps): slices per tail tile (1 = off),
 // number of whole tiles, and the floats of slab scratch it needs.
 void fv_conv_tail_plan(int M, int Nout, int ksteps, int* tail_f, int* tail_full, long long* slab_floats);

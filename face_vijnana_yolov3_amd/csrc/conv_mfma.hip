@@ -602,7 +602,14 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
 
 int fv_conv_mtiles(int M, int Nout) { (void)Nout; return (M + BM - 1) / BM; }
 
+bool fv_conv_narrow(int M, int Nout, int ksteps) {
+    if (Nout <= 64 || (Nout & 31) || ksteps < 8 || ksteps > 16) return false;
+    const int mt = (M + BM - 1) / BM;
+    return mt * ((Nout + 127) / 128) < 64 && mt * (Nout / 32) >= 48;
+}
+
 int fv_conv_choose_ksplit(int M, int Nout, int ksteps) {
+    if (fv_conv_narrow(M, Nout, ksteps)) return 1;
     const int bn = Nout > 64 ? 128 : (Nout > 32 ? 64 : 32);
     const int tiles = ((M + BM - 1) / BM) * ((Nout + bn - 1) / bn);
     if (tiles >= 192 || ksteps < 8) return 1;         // enough tiles to fill 256 CUs, or nothing to split
@@ -670,6 +677,7 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
     }
     for (int c = 0; c < a.nclass; ++c)
         FV_REQUIRE(ctx, a.taps[c].n >= 1 && a.taps[c].n <= 9, "conv: bad tap count");
+    if (a.narrow) return launch_cfg<32, 4, 1, false>(ctx, a);
     // 128-wide tiles: 8 waves (2 x 4, each 64 x 32) put four waves on every SIMD instead of two: the same per-element fmaf
     // chain (bit-identical outputs), 129 against 121 TF on the 52x52 layers
     if (a.Nout > 64) return ctx->conv_waves8 ? launch_cfg<128, 2, 4, false>(ctx, a) : launch_cfg<128, 2, 2, false>(ctx, a);
