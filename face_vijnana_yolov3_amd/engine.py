@@ -187,17 +187,46 @@ class Engine(object):
         self.adam_step(lr, beta_1, beta_2, decay)
         return loss
 
-    # ------------------------------------------------------------------ checkpoint (own format)
-    def save(self, path):
-        """Weights + BN moving stats + Adam state (the information Keras' model.save keeps,
-        fd.py:630).  Plain .npz; Keras-HDF5 interop is a SURVEY 8f 'next' row."""
-        d = dict(params=self.params.cpu().numpy(), state=self.state.cpu().numpy(), iterations=np.int64(self.iterations))
+    # ------------------------------------------------------------------ checkpoint (fd.py:630 model.save / fd.py:337 load_model)
+    def save(self, path, nested='model_1'):
+        """Weights + BN moving statistics + Adam state.  `*.h5` (the reference's MODEL_PATH / yolov3_base.h5 names) is written as a
+        real HDF5 file in Keras' weight layout (weights.write_keras_h5 through the pure-Python hdf5_lite: `model.load_weights`
+        of the reference's stack and h5py read it), with this build's Adam vectors and step count under /fv; any other
+        extension gets the plain .npz of rounds 1-2.  nested=None writes the one-group-per-layer layout of yolov3_base.h5."""
+        d = dict(iterations=np.int64(self.iterations))
+        if self.m is not None:
+            d['adam_m'] = self.m.cpu().numpy(); d['adam_v'] = self.v.cpu().numpy()
+        if str(path).endswith('.h5'):
+            from . import weights
+            weights.write_keras_h5(path, self.layers, self.params.cpu().numpy(), self.state.cpu().numpy(), nested=nested, extras=d)
+            return
+        d = dict(params=self.params.cpu().numpy(), state=self.state.cpu().numpy(), iterations=d['iterations'])
         if self.m is not None:
             d['m'] = self.m.cpu().numpy(); d['v'] = self.v.cpu().numpy()
         with open(path, 'wb') as f:
             np.savez(f, **d)
 
-    def load(self, path):
+    def load(self, path, require_all=True):
+        """HDF5 (a Keras weight / model file: the reference's face_detector.h5 or yolov3_base.h5, or one written by save) or the
+        .npz of rounds 1-2 -- told apart by the file signature.  require_all=False accepts a file that holds only some layers (the
+        base file loaded into the detector: the head keeps its current values)."""
+        from . import weights
+        from .hdf5_lite import is_hdf5
+        if is_hdf5(path):
+            p, st, found = None, None, None
+            from .hdf5_lite import read_hdf5
+            datasets, _ = read_hdf5(path)
+            p, st, found = weights.from_keras_datasets(datasets, self.layers, self.n_params, self.n_state,
+                                                       self.params.cpu().numpy(), self.state.cpu().numpy())
+            missing = sorted(set(weights.expected_keras_tensors(self.layers)) - set(found))
+            if missing and require_all:
+                raise FvError('%s lacks %d tensors of this model, e.g. %r' % (path, len(missing), missing[:3]))
+            self.set_params(torch.from_numpy(p), torch.from_numpy(st))
+            self.iterations = int(datasets['/fv/iterations']) if '/fv/iterations' in datasets else 0
+            if '/fv/adam_m' in datasets and '/fv/adam_v' in datasets:
+                self.ensure_optimizer()
+                self.m.copy_(torch.from_numpy(np.asarray(datasets['/fv/adam_m']))); self.v.copy_(torch.from_numpy(np.asarray(datasets['/fv/adam_v'])))
+            return
         with open(path, 'rb') as f:
             d = np.load(f)
             self.set_params(torch.from_numpy(d['params']), torch.from_numpy(d['state']))

@@ -5,7 +5,9 @@ network and the detect post-processing on MI355X through the C ABI.
 Same constructor (`conf = json['fd_conf']`), same methods, same config keys, same side-effect
 files (solution csv with 6 columns and no header, <test_path>/results/*_detected.jpg,
 ratios.csv, the model files).  Differences, all documented in DESIGN.md:
-  * model files are .npz written by Engine.save (no HDF5 library offline); names are kept
+  * model files are real HDF5 in Keras' WEIGHT layout (hdf5_lite.py, a pure-Python reader/writer: no HDF5 library in the
+    main interpreter): the reference's `model.load_weights` / h5py read them and the reference's face_detector.h5 /
+    yolov3_base.h5 load here; there is no `model_config`, so Keras' `load_model` does not take them
   * the grid is image_size/32 (the reference hard-codes 13, consistent only at 416)
   * multi_gpu=True means one process per GPU (torchrun) with RCCL all-reduce instead of
     keras.utils.multi_gpu_model towers; launched as a single process it trains on one GPU
@@ -90,12 +92,12 @@ class FaceDetector(object):
         from . import weights
         eng = self.model
         if self.conf.get('yolov3_base_model_load') and os.path.exists(self.BASE_MODEL_PATH):
-            eng.load(self.BASE_MODEL_PATH)
+            eng.load(self.BASE_MODEL_PATH, require_all=False)        # the base file holds no head (fd.py:393-396)
         elif os.path.exists(self.DARKNET_WEIGHTS_PATH):
             p, s = weights.read_darknet_base(self.DARKNET_WEIGHTS_PATH, eng.layers, eng.n_params, eng.n_state)
             eng.set_params(p, s)
-            if self.rank == 0:
-                eng.save(self.BASE_MODEL_PATH)
+            if self.rank == 0:                                       # base.save('yolov3_base.h5') (fd.py:596-598)
+                weights.write_keras_h5(self.BASE_MODEL_PATH, eng.layers[:-1], p, s, nested=None)
         else:
             print('FaceDetector: neither %s nor %s found; using synthetic base weights'
                   % (self.BASE_MODEL_PATH, self.DARKNET_WEIGHTS_PATH))
@@ -110,9 +112,14 @@ class FaceDetector(object):
         base = m.layers[:52]
         n_p = base[-1]['beta_off'] + base[-1]['cout']; n_s = base[-1]['var_off'] + base[-1]['cout']
         if self.conf.get('yolov3_base_model_load') and os.path.exists(self.BASE_MODEL_PATH):
-            with open(self.BASE_MODEL_PATH, 'rb') as f:
-                d = np.load(f)
-                m.load_base(d['params'][:n_p], d['state'][:n_s])
+            from .hdf5_lite import is_hdf5, read_hdf5
+            if is_hdf5(self.BASE_MODEL_PATH):
+                p, st, _found = weights.from_keras_datasets(read_hdf5(self.BASE_MODEL_PATH)[0], base, n_p, n_s)
+                m.load_base(p, st)
+            else:
+                with open(self.BASE_MODEL_PATH, 'rb') as f:
+                    d = np.load(f)
+                    m.load_base(d['params'][:n_p], d['state'][:n_s])
         elif os.path.exists(self.DARKNET_WEIGHTS_PATH):
             p, st = weights.read_darknet_base(self.DARKNET_WEIGHTS_PATH, base, n_p, n_s)
             m.load_base(p, st)

@@ -158,15 +158,38 @@ class Yolov3(object):
         return loss
 
     def save(self, path):
-        """Weights + BN moving statistics + Adam state, the npz layout of Engine.save (plus out_channels)."""
-        d = dict(params=self.params.cpu().numpy(), state=self.state.cpu().numpy(), iterations=np.int64(self.iterations),
-                 out_channels=np.int64(self.out_channels))
+        """As Engine.save: `*.h5` = HDF5 in Keras' weight layout, one group per layer as `make_yolov3_model().save_weights` names
+        them (conv_i / bnorm_i; the detection convs conv_81 / conv_93 / conv_105 carry a bias), Adam state under /fv."""
+        d = dict(iterations=np.int64(self.iterations), out_channels=np.int64(self.out_channels))
+        if self.m is not None:
+            d['adam_m'] = self.m.cpu().numpy(); d['adam_v'] = self.v.cpu().numpy()
+        if str(path).endswith('.h5'):
+            from . import weights
+            weights.write_keras_h5(path, self.layers, self.params.cpu().numpy(), self.state.cpu().numpy(), nested=None, extras=d)
+            return
+        d = dict(params=self.params.cpu().numpy(), state=self.state.cpu().numpy(), iterations=d['iterations'], out_channels=d['out_channels'])
         if self.m is not None:
             d['m'] = self.m.cpu().numpy(); d['v'] = self.v.cpu().numpy()
         with open(path, 'wb') as f:
             np.savez(f, **d)
 
     def load(self, path):
+        from . import weights
+        from .hdf5_lite import is_hdf5, read_hdf5
+        if is_hdf5(path):
+            datasets, _ = read_hdf5(path)
+            if '/fv/out_channels' in datasets and int(datasets['/fv/out_channels']) != self.out_channels:
+                raise ValueError('%s holds a model with %d output channels, this one has %d' % (path, int(datasets['/fv/out_channels']), self.out_channels))
+            p, st, found = weights.from_keras_datasets(datasets, self.layers, self.n_params, self.n_state)
+            missing = sorted(set(weights.expected_keras_tensors(self.layers)) - set(found))
+            if missing:
+                raise ValueError('%s lacks %d tensors of this model, e.g. %r' % (path, len(missing), missing[:3]))
+            self.set_params(torch.from_numpy(p), torch.from_numpy(st))
+            self.iterations = int(datasets['/fv/iterations']) if '/fv/iterations' in datasets else 0
+            if '/fv/adam_m' in datasets and '/fv/adam_v' in datasets:
+                self.ensure_optimizer()
+                self.m.copy_(torch.from_numpy(np.asarray(datasets['/fv/adam_m']))); self.v.copy_(torch.from_numpy(np.asarray(datasets['/fv/adam_v'])))
+            return
         with open(path, 'rb') as f:
             d = np.load(f)
             if 'out_channels' in d and int(d['out_channels']) != self.out_channels:

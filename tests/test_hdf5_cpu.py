@@ -1,0 +1,120 @@
+"""SURVEY 8f row 2 -- Keras-HDF5 interop (reference face_detection.py:337, 394, 598, 630: load_model / model.save of
+face_detector.h5 and yolov3_base.h5).  The main interpreter has no HDF5 library, so the container is read and written by
+face_vijnana_yolov3_amd/hdf5_lite.py.  Pinned by files libhdf5 itself wrote in Keras 2.2.4's weight layout
+(tests/golden/keras_layout_*.h5, minted by tests/golden/make_h5_fixture.py under the build container's second interpreter, the
+only place h5py exists); the writer is checked by reading its files back with h5py when that interpreter is present.
+PARITY UNPINNED against a file written by Keras itself (not installed; the reference's pretrained files are download-only)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from face_vijnana_yolov3_amd import hdf5_lite, weights
+
+H5PY_PYTHON = '/opt/conda/bin/python3.9'
+
+
+def _golden(golden_dir):
+    return {k.replace('|', '/'): v for k, v in np.load(os.path.join(golden_dir, 'keras_layout.npz')).items()}
+
+
+@pytest.mark.parametrize('tag', ['detector', 'base', 'wide'])
+def test_reader_returns_what_libhdf5_wrote(golden_dir, tag):
+    want = {k[len(tag):]: v for k, v in _golden(golden_dir).items() if k.startswith(tag + '/')}
+    data, attrs = hdf5_lite.read_hdf5(os.path.join(golden_dir, 'keras_layout_%s.h5' % tag))
+    assert set(data) == set(want)
+    for k, v in data.items():
+        assert v.dtype == want[k].dtype and np.shape(v) == want[k].shape and np.array_equal(v, want[k]), k
+    names = attrs['/model_weights']['layer_names']
+    if tag == 'detector':
+        assert [n.decode() for n in names] == ['input1', 'model_1', 'output']
+        assert attrs['/']['keras_version'] in ('2.2.4', b'2.2.4') and json.loads(attrs['/']['model_config'])['class_name'] == 'Model'
+        assert [n.decode() for n in attrs['/model_weights/output']['weight_names']] == ['output/kernel:0', 'output/bias:0']
+        assert data['/optimizer_weights/Adam/iterations:0'] == 1234
+    if tag == 'wide':
+        assert len(names) == 300 and names[299] == b'layer_299'            # several symbol-table nodes, chunked dataset
+        assert data['/chunked'].shape == (40, 6) and data['/chunked'].dtype == np.int32
+
+
+def _tiny_layers():
+    layers, off, soff = [], 0, 0
+    for idx, k, cin, cout in [(0, 3, 3, 4), (1, 3, 4, 8), (2, 1, 8, 4), (3, 3, 4, 8)]:
+        d = dict(darknet_index=idx, ksize=k, cin=cin, cout=cout, has_bn=1, w_off=off)
+        off += cout * k * k * cin
+        d['gamma_off'] = off; off += cout
+        d['beta_off'] = off; off += cout
+        d['mean_off'] = soff; soff += cout
+        d['var_off'] = soff; soff += cout
+        layers.append(d)
+    h = dict(darknet_index=-1, ksize=3, cin=8, cout=6, has_bn=0, w_off=off, gamma_off=-1, mean_off=-1, var_off=-1)
+    off += 6 * 9 * 8
+    h['beta_off'] = off; off += 6
+    layers.append(h)
+    return layers, off, soff
+
+
+def test_keras_layout_maps_onto_the_flat_vectors(golden_dir):
+    """face_detector.h5 layout (nested base model + head) and yolov3_base.h5 layout (one group per Keras layer): kernels HWIO ->
+    OHWI, BatchNormalization weights gamma / beta / moving_mean / moving_variance (keras_weights() is the inverse, pinned by the
+    WeightReader golden)."""
+    layers, n_p, n_s = _tiny_layers()
+    g = _golden(golden_dir)
+    p, s, extras = weights.read_keras_h5(os.path.join(golden_dir, 'keras_layout_detector.h5'), layers, n_p, n_s)
+    kw = weights.keras_weights(layers, p, s)
+    for d in layers[:-1]:
+        i = d['darknet_index']
+        assert np.array_equal(kw['conv_%d' % i][0], g['detector/model_weights/model_1/conv_%d/kernel:0' % i])
+        for j, n in enumerate(('gamma', 'beta', 'moving_mean', 'moving_variance')):
+            assert np.array_equal(kw['bnorm_%d' % i][j], g['detector/model_weights/model_1/bnorm_%d/%s:0' % (i, n)])
+    assert np.array_equal(kw['output'][0], g['detector/model_weights/output/output/kernel:0'])
+    assert np.array_equal(kw['output'][1], g['detector/model_weights/output/output/bias:0']) and extras == {}
+    # the base file lacks the head: refused when everything is required, accepted otherwise
+    with pytest.raises(ValueError):
+        weights.read_keras_h5(os.path.join(golden_dir, 'keras_layout_base.h5'), layers, n_p, n_s)
+    pb, sb, _ = weights.read_keras_h5(os.path.join(golden_dir, 'keras_layout_base.h5'), layers, n_p, n_s, require_all=False)
+    kb = weights.keras_weights(layers, pb, sb)
+    assert np.array_equal(kb['conv_3'][0], g['base/model_weights/conv_3/conv_3/kernel:0'])
+    assert np.array_equal(kb['bnorm_2'][3], g['base/model_weights/bnorm_2/bnorm_2/moving_variance:0']) and not kb['output'][0].any()
+
+
+def test_writer_round_trip_and_libhdf5_reads_it(tmp_path):
+    layers, n_p, n_s = _tiny_layers()
+    rng = np.random.default_rng(3)
+    p = rng.standard_normal(n_p).astype(np.float32); s = rng.standard_normal(n_s).astype(np.float32)
+    extras = {'iterations': np.int64(42), 'adam_m': rng.standard_normal(n_p).astype(np.float32)}
+    for nested, name in (('model_1', 'face_detector.h5'), (None, 'yolov3_base.h5')):
+        path = str(tmp_path / name)
+        weights.write_keras_h5(path, layers, p, s, nested=nested, extras=extras)
+        p2, s2, ex = weights.read_keras_h5(path, layers, n_p, n_s)
+        assert np.array_equal(p, p2) and np.array_equal(s, s2) and int(ex['iterations']) == 42 and np.array_equal(ex['adam_m'], extras['adam_m'])
+        _, attrs = hdf5_lite.read_hdf5(path)
+        names = [n.decode() for n in attrs['/model_weights']['layer_names']]
+        assert names == (['input1', 'model_1', 'output'] if nested else ['conv_0', 'bnorm_0', 'conv_1', 'bnorm_1', 'conv_2', 'bnorm_2', 'conv_3', 'bnorm_3', 'output'])
+        if not os.path.exists(H5PY_PYTHON):
+            continue
+        code = ('import h5py, json, numpy as np\n'
+                'f = h5py.File(%r, "r"); g = f["model_weights"]\n'
+                'out = {}\n'
+                'f.visititems(lambda n, o: out.__setitem__("/" + n, np.asarray(o[()]).ravel()[:3].tolist()) if isinstance(o, h5py.Dataset) else None)\n'
+                'print(json.dumps(dict(layers=[x.decode() for x in g.attrs["layer_names"]], kv=bytes(f.attrs["keras_version"]).decode(), data=out,\n'
+                '    wn=[x.decode() for x in g[g.attrs["layer_names"][-1].decode()].attrs["weight_names"]])))\n') % path
+        r = subprocess.run([H5PY_PYTHON, '-c', code], capture_output=True, text=True, timeout=120)
+        if r.returncode != 0 and 'No module named' in r.stderr:
+            continue
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = json.loads(r.stdout)
+        assert got['layers'] == names and got['kv'] == '2.2.4' and got['wn'] == ['output/kernel:0', 'output/bias:0']
+        mine, _ = hdf5_lite.read_hdf5(path)
+        assert set(got['data']) == set(mine)
+        for k, v in got['data'].items():
+            assert np.allclose(np.asarray(mine[k]).ravel()[:3], v, rtol=0, atol=0), k
+
+
+def test_rejects_what_it_does_not_implement(tmp_path):
+    with pytest.raises(hdf5_lite.H5Error):
+        hdf5_lite.read_hdf5(b'not an hdf5 file at all' * 100)
+    assert not hdf5_lite.is_hdf5(__file__)
+    with pytest.raises(NotImplementedError):
+        hdf5_lite.write_hdf5(str(tmp_path / 'x.h5'), {'/a': np.zeros(3, np.complex64)})
