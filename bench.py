@@ -332,16 +332,19 @@ def rccl_world1_rehearsal(eng, x, y, steps=10):
         return None
     try:
         # an in-process store: under torch.distributed.run a tcp:// rendezvous would try to join the elastic agent's store
+        def timed(fn):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3
+        plain_ms = timed(lambda: eng.train_on_batch(x, y, **HPS))           # the same loop without the DP machinery, for comparison
         dist.init_process_group('nccl', store=dist.HashStore(), rank=0, world_size=1, device_id=eng.dev)
         tr = DataParallelTrainer(eng, world_size=1, rank=0, force_bucket_path=True)
-        for _ in range(3):
-            tr.train_on_batch(x, y, **HPS)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            tr.train_on_batch(x, y, **HPS)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
+        ms = timed(lambda: tr.train_on_batch(x, y, **HPS))
         tr.time_comm = True                     # a second pass brackets every collective with events on the comm stream
         tr.comm_ms()
         for _ in range(3):
@@ -351,7 +354,7 @@ def rccl_world1_rehearsal(eng, x, y, steps=10):
         tr.time_comm = False
         out = dict(rccl_ranks=dist.get_world_size(), backend=dist.get_backend(), bucket_mib=tr.bucket_bytes >> 20,
                    gradient_mb=round(eng.n_params * 4 / 1e6, 2), collectives_per_step=n_coll + 1, allreduce_ms=round(ar, 3),
-                   ms_per_step=round(ms, 3), steps=steps,
+                   ms_per_step=round(ms, 3), plain_ms_per_step_same_loop=round(plain_ms, 3), steps=steps,
                    note='world-size-1 nccl group on this GPU: bucketed all_reduce calls on the comm stream overlapped with backward')
         dist.destroy_process_group()
         return out

@@ -68,7 +68,16 @@ class DataParallelTrainer(object):
         self._comm_events = []
         self.bucketed = self.world > 1 or force_bucket_path  # force: exercise the stream/bucket path on 1 GPU
         if self.bucketed:
-            self.comm = torch.cuda.Stream(device=engine.dev)
+            # The collectives run on their own stream, concurrently with the rest of the backward pass.  A/B knobs (measured on one
+            # MI355X with a world-size-1 RCCL group, tools/dp_overhead2.py: default 56.4 ms per step against 53.4 plain --
+            # RCCL's kernels and the matrix kernels share the CUs --, FV_COMM_PRIORITY=-1 66.3, GPU_MAX_HW_QUEUES=8 61.7):
+            # FV_COMM_STREAM=main enqueues them on the compute stream instead (no concurrency: the all-reduce time is exposed,
+            # nothing else is slowed); FV_COMM_PRIORITY sets the stream priority (-1 = high).  Which wins on 8 GPUs is a
+            # measurement the first multi-GPU run has to make (bench.py reports exposed_comm_ms per rank).
+            if os.environ.get('FV_COMM_STREAM', 'side') == 'main':
+                self.comm = torch.cuda.current_stream(engine.dev)
+            else:
+                self.comm = torch.cuda.Stream(device=engine.dev, priority=int(os.environ.get('FV_COMM_PRIORITY', '0')))
             engine.ensure_optimizer()
             self.reducer = BucketReducer(engine.grads, self.world, bucket_bytes, self._launch)
         self._own_group = False

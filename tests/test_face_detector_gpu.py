@@ -96,6 +96,10 @@ def test_tiny_train_save_load(tmp_path, monkeypatch):
     assert conf['hps']['step'] == 3 and fd.model.iterations == 6
     assert not torch.equal(p0, fd.model.params) and torch.isfinite(fd.model.params).all()
     assert os.path.exists(FaceDetector.MODEL_PATH)
+    from face_vijnana_yolov3_amd import hdf5_lite
+    assert hdf5_lite.is_hdf5(FaceDetector.MODEL_PATH)                 # a real HDF5 file in Keras' weight layout (fd.py:630)
+    _, attrs = hdf5_lite.read_hdf5(FaceDetector.MODEL_PATH)
+    assert [n.decode() for n in attrs['/model_weights']['layer_names']] == ['input1', 'model_1', 'output']
     conf2 = _conf(root, 'test', image_size=96); conf2['model_loading'] = True
     fd2 = FaceDetector(conf2)
     assert torch.equal(fd2.model.params, fd.model.params) and torch.equal(fd2.model.state, fd.model.state)
