@@ -224,11 +224,17 @@ def loader_bench(eng, trainer, B, S, steps):
         hps = dict(HPS, batch_size=B, step=1)
         seq = data.TrainingSequence(root, hps, {'image_size': S, 'bb_info_c_size': 6})
         threads = min(16, max(2, (os.cpu_count() or 8) // 2))
-        feeder = BatchFeeder(seq, 1, 0, threads)
-        t0 = time.perf_counter()
-        for k in range(2):
-            feeder.load(k % len(seq))
-        loader_only = 2 * B / (time.perf_counter() - t0)
+        def loader_rate(f):
+            f.load(0)                                  # warm-up: file cache, pinned buffers
+            t0 = time.perf_counter()
+            for k in range(2):
+                f.load(k % len(seq))
+            return 2 * B / (time.perf_counter() - t0)
+        pil = BatchFeeder(data.TrainingSequence(root, dict(hps, device_jpeg=False), {'image_size': S, 'bb_info_c_size': 6}), 1, 0, threads)
+        loader_only_pillow = loader_rate(pil)
+        pil.close()
+        feeder = BatchFeeder(seq, 1, 0, threads)       # default: Huffman decoding on the host, the rest of the JPEG decode on the device
+        loader_only = loader_rate(feeder)
         feeder.prefetch(0)
         for k in range(2):                             # warm-up
             item = feeder.take(); feeder.prefetch((k + 1) % len(seq))
@@ -242,9 +248,12 @@ def loader_bench(eng, trainer, B, S, steps):
         dt = time.perf_counter() - t0
         feeder.take(); feeder.close()
     return dict(value=round(B * steps / dt, 2), unit='images/sec', ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
-                loader_only_images_per_sec=round(loader_only, 1), loader_threads=threads,
-                path='%d synthetic UCCS-format JPEGs (768x1024 .. 720x1280): PIL decode on host threads -> one pinned buffer -> '
-                     'H2D -> fv_letterbox_batch (one launch) -> fv_train_step + Adam; batch k+1 decoded while step k runs' % n_img)
+                loader_only_images_per_sec=round(loader_only, 1), loader_only_pillow_images_per_sec=round(loader_only_pillow, 1),
+                loader_threads=threads,
+                path='%d synthetic UCCS-format JPEGs (768x1024 .. 720x1280): Huffman decoding on host threads (fv_jpeg_entropy_decode) '
+                     '-> quantised coefficients in one pinned buffer -> H2D -> fv_jpeg_reconstruct_batch (IDCT, chroma upsampling, '
+                     'colour conversion on the device) -> fv_letterbox_batch -> fv_train_step + Adam; batch k+1 decoded while step k '
+                     'runs; loader_only_pillow = the same loader with the whole decode in Pillow on the host' % n_img)
 
 
 def test_loop_bench(device, S, n_img=64):
@@ -283,8 +292,8 @@ def test_loop_bench(device, S, n_img=64):
         finally:
             face_detection.DEBUG = dbg
     return dict(unit='images/sec', eval_batch_1=out['batch1'], eval_batch_16=out['batch16'], images=n_img, csv_rows=rows,
-                path='FaceDetector.test(): %d synthetic JPEGs (768x1024 .. 720x1280), PIL decode on 16 host threads one batch ahead, '
-                     'fv_letterbox_batch, fv_forward_infer, fv_decode_nms, back-projection, csv' % n_img)
+                path='FaceDetector.test(): %d synthetic JPEGs (768x1024 .. 720x1280), Huffman decoding on 16 host threads one batch '
+                     'ahead, fv_jpeg_reconstruct_batch, fv_letterbox_batch, fv_forward_infer, fv_decode_nms, back-projection, csv' % n_img)
 
 
 def three_scale_bench(device, S, B=16, steps=3):

@@ -14,6 +14,9 @@ ratios.csv, the model files).  Differences, all documented in DESIGN.md:
   * evaluate() tolerates images without ground-truth rows and a missing arial.ttf
   * evaluate()/test() read ahead and run the network on batches of hps['eval_batch_size'] images (default 16; the
     reference's loop is batch 1, fd.py:632-883) -- same rows in the same order
+  * train() and test() decode baseline JPEGs in two halves (jpeg.py): Huffman decoding on host threads, dequantisation / IDCT /
+    chroma upsampling / colour conversion on the device, bit-identical to Pillow's pixels (hps['device_jpeg'] = false: Pillow);
+    evaluate() draws on the image and keeps decoding it with Pillow
   * nn_arch['head'] = 'three_scale' (default 'single' = the reference's 13x13x6 head) selects the full three-scale YOLOv3
     graph (yolov3_detect.py:217-311) with nn_arch['num_classes'] (default 1) classes: trained with the build's
     objectness / box / class loss on targets from data.encode_gt_three_scale, detected through the reference's
@@ -238,7 +241,7 @@ class FaceDetector(object):
         names = sorted(glob.glob(os.path.join(test_path, '*.jpg')))
         return shard_files(names, self.world, self.rank) if self.world > 1 else names
 
-    def _detect_files(self, files):
+    def _detect_files(self, files, need_raw=True):
         """Yield (file_name, raw image, boxes in image coordinates) in file order.  The reference's evaluate()/test() loops
         (fd.py:632-883) decode, letterbox and predict one image at a time; here a thread pool decodes batch k+1 (PIL releases
         the GIL) while batch k is letterboxed in one launch (fv_letterbox_batch) and runs ONE forward + ONE decode/NMS launch
@@ -248,17 +251,33 @@ class FaceDetector(object):
         if not chunks:
             return
         threads = max(1, min(bs, int(self.hps.get('loader_threads', 8))))
+        use_jpeg = not need_raw and bool(self.hps.get('device_jpeg', True))
         with ThreadPoolExecutor(max_workers=threads) as pool, ThreadPoolExecutor(max_workers=1) as one:
-            load = lambda chunk: list(pool.map(data._pil_loader, chunk))
+            def load(chunk):
+                if use_jpeg:       # test() never looks at the pixels on the host: Huffman-decode only, the rest on the device
+                    import torch
+                    from . import jpeg
+                    datas = list(pool.map(lambda f: open(f, 'rb').read(), chunk))
+                    infos = [jpeg.parse(d) for d in datas]
+                    if all(i is not None for i in infos):
+                        plan = jpeg.BatchPlan(infos)
+                        buf = torch.empty(plan.total_coefs, dtype=torch.int16)
+                        if torch.cuda.is_available():
+                            buf = buf.pin_memory()
+                        view = buf.numpy()
+                        list(pool.map(lambda i: jpeg.entropy_decode(datas[i], infos[i], view[plan.coef_off[i]:plan.coef_off[i] + int(infos[i].total_coefs)]),
+                                      range(len(chunk))))
+                        return None, ('jpeg', buf, plan)
+                return list(pool.map(data._pil_loader, chunk)), None
             pending = one.submit(load, chunks[0])
             for k, chunk in enumerate(chunks):
-                raws = pending.result()
+                raws, packed = pending.result()
                 if k + 1 < len(chunks):
                     pending = one.submit(load, chunks[k + 1])
-                x, geoms = letterbox_batch_device(self.model.ctx, raws, self.image_size, self.model.dev)
-                for name, raw, boxes, geom in zip(chunk, raws, self.detect_batch(x), geoms):
+                x, geoms = letterbox_batch_device(self.model.ctx, raws, self.image_size, self.model.dev, packed=packed)
+                for i, (name, boxes, geom) in enumerate(zip(chunk, self.detect_batch(x), geoms)):
                     self._project_back(boxes, geom)
-                    yield name, raw, boxes
+                    yield name, (raws[i] if raws is not None else None), boxes
 
     def evaluate(self):
         import pandas as pd
@@ -317,7 +336,7 @@ class FaceDetector(object):
         if self.world > 1:
             ensure_process_group(self.model.dev)
         with open(part_path(out_path, self.world, self.rank), 'w') as f:
-            for n, (file_name, _raw, boxes) in enumerate(self._detect_files(files)):
+            for n, (file_name, _raw, boxes) in enumerate(self._detect_files(files, need_raw=False)):
                 if DEBUG:
                     print(n + 1, '/', len(files), file_name)
                 self._write_rows(f, file_name, boxes)
@@ -335,12 +354,35 @@ class BatchFeeder(object):
         self.seq, self.world, self.rank = seq, world, rank
         self.pool = ThreadPoolExecutor(max_workers=max(1, threads))
         self.one = ThreadPoolExecutor(max_workers=1)
+        self.device_jpeg = bool(seq.hps.get('device_jpeg', True))    # hps.device_jpeg = false: decode with Pillow on the host
         self.pending = None
         # three pinned staging buffers, reused round-robin (allocating ~100 MB of pinned memory per batch costs more than
         # decoding it); a buffer is rewritten only after the H2D copy that read it has completed (event recorded by the consumer)
         self._pins = [None, None, None]
         self._pin_events = [None, None, None]
         self._pin_next = 0
+
+    def _load_jpeg(self, seq, names, pin):
+        """The batch as quantised JPEG coefficients (jpeg.py): the files are read and Huffman-decoded by the pool straight into
+        one pinned int16 buffer; dequantisation, IDCT, chroma upsampling and colour conversion happen on the device.  None when a
+        file is not a baseline JPEG this decoder takes (the batch then goes through Pillow)."""
+        import torch
+        from . import jpeg
+        datas = list(self.pool.map(lambda nm: open(os.path.join(seq.raw_data_path, nm), 'rb').read(), names))
+        infos = [jpeg.parse(d) for d in datas]
+        if any(i is None for i in infos):
+            return None
+        plan = jpeg.BatchPlan(infos)
+        slot = None
+        if pin:
+            slot, raw = self._pinned(2 * plan.total_coefs)
+            buf = raw.view(torch.int16)
+        else:
+            buf = torch.empty(plan.total_coefs, dtype=torch.int16)
+        view = buf.numpy()
+        list(self.pool.map(lambda i: jpeg.entropy_decode(datas[i], infos[i], view[plan.coef_off[i]:plan.coef_off[i] + int(infos[i].total_coefs)]),
+                           range(len(names))))
+        return ('jpeg', buf, plan), [(i.height, i.width) for i in infos], slot
 
     def _pinned(self, nbytes):
         import torch
@@ -371,7 +413,10 @@ class BatchFeeder(object):
         lo, hi, weight = sl
         mine = names[lo:hi]
         pin = torch.cuda.is_available()
-        if seq.loader is data._pil_loader:
+        jp = self._load_jpeg(seq, mine, pin) if (seq.loader is data._pil_loader and self.device_jpeg) else None
+        if jp is not None:
+            packed, shapes, slot = jp
+        elif seq.loader is data._pil_loader:
             # sizes from the JPEG headers first, then every worker decodes its image straight into its
             # slice of the one pinned buffer (no second pass over ~100 MB per batch on one thread)
             from PIL import Image

@@ -110,10 +110,18 @@ def letterbox_batch_device(ctx, raws, image_size, device, out=None, packed=None)
     (fv_letterbox_batch); `packed` = the result of pack_images when a loader thread prepared it."""
     import ctypes
     import torch
-    buf, offs, hw = packed if packed is not None else pack_images(raws)
+    if packed is not None and isinstance(packed[0], str) and packed[0] == 'jpeg':
+        # ('jpeg', int16 host tensor of quantised coefficients, jpeg.BatchPlan): the images are reconstructed on the device
+        # (fv_jpeg_reconstruct_batch) straight into the packed RGB buffer this launch reads -- no RGB image on the host
+        from . import jpeg
+        _tag, coefs, plan = packed
+        dbuf = jpeg.reconstruct_batch(ctx, plan, coefs.to(device, non_blocking=True), device)
+        offs, hw = plan.rgb_off, plan.hw
+    else:
+        buf, offs, hw = packed if packed is not None else pack_images(raws)
+        dbuf = buf.to(device, non_blocking=True)
     n = len(offs)
     S = int(image_size)
-    dbuf = buf.to(device, non_blocking=True)
     if out is None:
         out = torch.empty((n, S, S, 3), dtype=torch.float32, device=device)
     geom = (ctypes.c_int32 * (6 * n))()

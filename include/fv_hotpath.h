@@ -270,6 +270,36 @@ int fv_letterbox(fv_ctx* ctx, const uint8_t* src, int h, int w, int image_size, 
 int fv_letterbox_batch(fv_ctx* ctx, const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
                        int image_size, float* dst, int32_t* geom);
 
+/* ------------------------------------------------------------------ JPEG decode, split host / device
+ * (replaces `imread` of fd.py:112, 656, 798 for baseline / extended-sequential Huffman JPEGs with 1 or 3
+ * components and 4:4:4 / 4:2:2 / 4:2:0 sampling; anything else -> FV_ERR_INVALID and the caller decodes that file elsewhere).
+ * The host part (no context, thread-safe, pure CPU) parses the headers and Huffman-decodes the scan into quantised coefficients:
+ * int16, natural (de-zigzagged) order, [64] per block, component after component, each component's block grid padded to whole
+ * MCUs in raster order.  The device part dequantises, inverse-transforms (libjpeg's jpeg_idct_islow), upsamples the chroma
+ * (libjpeg's "fancy" triangle filters) and converts YCbCr -> RGB for a whole batch in two launches: pixels bit-identical to
+ * libjpeg-turbo's default decode (what Pillow / scikit-image return). */
+typedef struct fv_jpeg_info {
+    int32_t width, height, ncomp, hmax, vmax, restart_interval;
+    int32_t h[3], v[3], blocks_w[3], blocks_h[3];
+    int64_t coef_off[3];   /* first coefficient of component c, in int16 units from the image's coefficient array */
+    int64_t total_coefs;
+    uint16_t qt[3][64];    /* quantisation table of component c, natural order */
+} fv_jpeg_info;
+typedef struct fv_jpeg_desc {   /* one image of a batch; array in DEVICE memory */
+    int32_t width, height, ncomp, hmax, vmax, reserved;
+    int32_t blocks_w[3], blocks_h[3];
+    int64_t coef_off[3];   /* absolute, int16 units from `coefs` */
+    int64_t plane_off[3];  /* absolute, bytes from `planes` (component c needs blocks_w*blocks_h*64 bytes) */
+    int64_t rgb_off;       /* bytes from `rgb` (height*width*3 bytes, rows packed) */
+    uint16_t qt[3][64];
+} fv_jpeg_desc;
+int fv_jpeg_parse(const uint8_t* data, size_t nbytes, fv_jpeg_info* info);
+int fv_jpeg_entropy_decode(const uint8_t* data, size_t nbytes, int16_t* coefs, int64_t ncoefs);   /* HOST buffers */
+int64_t fv_jpeg_plane_bytes(const fv_jpeg_info* info);
+/* coefs, descs, planes (scratch), rgb: device; max_blocks / max_pixels: the largest block / pixel count of one image (grid size) */
+int fv_jpeg_reconstruct_batch(fv_ctx* ctx, const int16_t* coefs, const fv_jpeg_desc* descs, int n, uint8_t* planes, uint8_t* rgb,
+                              int64_t max_blocks, int64_t max_pixels);
+
 /* ------------------------------------------------------------------ secondary: three-scale YOLOv3
  * (SURVEY 8a-17/18).  The reference builds this graph in make_yolov3_model (yd.py:217-311) and
  * runs it only from yolov3_detect.py:_main_ (COCO demo: yd.py:596-598 decode, do_nms); FaceDetector
