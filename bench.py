@@ -68,6 +68,7 @@ def parse():
     ap.add_argument('--no-loader', action='store_true', help='skip the loader-inclusive measurement')
     ap.add_argument('--no-three-scale', action='store_true', help='skip the three-scale training measurement')
     ap.add_argument('--loader-steps', type=int, default=6)
+    ap.add_argument('--child-three-scale', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -429,6 +430,9 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.child_three_scale:                     # helper mode of the parent's three_scale_train section
+        print(json.dumps(three_scale_bench(0, args.image_size, steps=5)), flush=True)
+        return
     if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.spawn):
         sys.exit(self_launch(args))              # nothing above touched the GPU: the children own the devices
     # Rank 0's JSON line is the ONLY thing on stdout: C libraries write to fd 1 too (RCCL prints its version banner there at
@@ -561,7 +565,14 @@ def main():
             loader = loader_bench(eng, trainer, B, S, args.loader_steps)
         three = None
         if world == 1 and not args.no_three_scale and not args.no_detect:
-            three = three_scale_bench(local_rank, S)
+            # in a FRESH child process: measured in this one, after the other sections, the same step ran 41 instead of 31.6 ms
+            # (tools/stream_env_probe.py: not the stream pool, not RCCL, not further contexts -- a 10 GB workspace allocated late
+            # into a fragmented address space is the remaining suspect); this process only waits meanwhile
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--child-three-scale', '--image-size', str(S)],
+                               capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"value"')]
+            three = json.loads(line[-1]) if r.returncode == 0 and line else dict(error=(r.stderr or r.stdout)[-400:])
         dom_name, dom = dominant(prof)
         roofline = None
         traffic, traffic_source = pmc_traffic(B, S)

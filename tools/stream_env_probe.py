@@ -36,3 +36,12 @@ measure('after three more contexts')
 import bench
 bench.test_loop_bench(0, 416, n_img=16)
 measure('after a FaceDetector.test() loop')
+from face_vijnana_yolov3_amd import data
+eng = engs[0]
+x40 = torch.rand((40, 416, 416, 3)).cuda(); y40 = torch.from_numpy(data.synth_gt_batch(40, 416, seed=1)).cuda()
+for _ in range(3):
+    eng.train_on_batch(x40, y40, **bench.HPS)
+torch.cuda.synchronize()
+measure('after base training steps (13 GB workspace alive)')
+print(bench.rccl_world1_rehearsal(eng, x40, y40))
+measure('after bench.rccl_world1_rehearsal')
