@@ -226,11 +226,12 @@ def loader_bench(eng, trainer, B, S, steps):
         seq = data.TrainingSequence(root, hps, {'image_size': S, 'bb_info_c_size': 6})
         threads = min(16, max(2, (os.cpu_count() or 8) // 2))
         def loader_rate(f):
-            f.load(0)                                  # warm-up: file cache, pinned buffers
-            t0 = time.perf_counter()
-            for k in range(2):
+            for k in range(3):                         # warm-up: file cache and the three pinned staging buffers
                 f.load(k % len(seq))
-            return 2 * B / (time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            for k in range(4):
+                f.load(k % len(seq))
+            return 4 * B / (time.perf_counter() - t0)
         pil = BatchFeeder(data.TrainingSequence(root, dict(hps, device_jpeg=False), {'image_size': S, 'bb_info_c_size': 6}), 1, 0, threads)
         loader_only_pillow = loader_rate(pil)
         pil.close()

@@ -53,8 +53,8 @@ def parse(data):
     """JPEG bytes -> JpegInfo, or None when the file is not one this decoder takes (progressive, arithmetic-coded, CMYK, 12-bit,
     unusual sampling, damaged header)."""
     info = JpegInfo()
-    buf = (ctypes.c_char * len(data)).from_buffer_copy(data) if not isinstance(data, (bytes, bytearray)) else data
-    rc = _fn().fv_jpeg_parse(ctypes.c_char_p(bytes(buf)) if not isinstance(buf, bytes) else ctypes.c_char_p(buf), len(data), ctypes.byref(info))
+    data = data if isinstance(data, bytes) else bytes(data)
+    rc = _fn().fv_jpeg_parse(ctypes.c_char_p(data), len(data), ctypes.byref(info))
     return info if rc == 0 else None
 
 
@@ -65,6 +65,7 @@ def entropy_decode(data, info, out=None):
     if out is None:
         out = np.empty(n, np.int16)
     assert out.dtype == np.int16 and out.size >= n and out.flags['C_CONTIGUOUS']
+    data = data if isinstance(data, bytes) else bytes(data)
     rc = _fn().fv_jpeg_entropy_decode(ctypes.c_char_p(data), len(data), ctypes.c_void_p(out.ctypes.data), out.size)
     if rc != 0:
         raise ValueError('fv_jpeg_entropy_decode failed (%d): damaged scan data' % rc)
