@@ -226,17 +226,20 @@ def loader_bench(eng, trainer, B, S, steps):
         seq = data.TrainingSequence(root, hps, {'image_size': S, 'bb_info_c_size': 6})
         threads = min(16, max(2, (os.cpu_count() or 8) // 2))
         def loader_rate(f):
-            for k in range(3):                         # warm-up: file cache and the three pinned staging buffers
-                f.load(k % len(seq))
             t0 = time.perf_counter()
-            for k in range(4):
+            for k in range(3):
                 f.load(k % len(seq))
-            return 4 * B / (time.perf_counter() - t0)
+            return 3 * B / (time.perf_counter() - t0)
+        # loader alone, both decoders, interleaved A/B/A/B after a warm-up of each (file cache, three pinned staging buffers each);
+        # best of two: the host share of a 1-GPU box is noisy
         pil = BatchFeeder(data.TrainingSequence(root, dict(hps, device_jpeg=False), {'image_size': S, 'bb_info_c_size': 6}), 1, 0, threads)
-        loader_only_pillow = loader_rate(pil)
-        pil.close()
         feeder = BatchFeeder(seq, 1, 0, threads)       # default: Huffman decoding on the host, the rest of the JPEG decode on the device
-        loader_only = loader_rate(feeder)
+        loader_rate(pil); loader_rate(feeder)
+        loader_only_pillow = loader_only = 0.0
+        for _ in range(2):
+            loader_only_pillow = max(loader_only_pillow, loader_rate(pil))
+            loader_only = max(loader_only, loader_rate(feeder))
+        pil.close()
         feeder.prefetch(0)
         for k in range(2):                             # warm-up
             item = feeder.take(); feeder.prefetch((k + 1) % len(seq))
