@@ -35,8 +35,10 @@ def main():
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--only', default='')
     ap.add_argument('--scratch-mib', type=int, default=0, help='lend conv scratch (enables the tail split at op level)')
+    ap.add_argument('--waves8', type=int, default=1, help='0: the 4-wave forms of the 128- and 64-wide conv tiles')
     a = ap.parse_args()
     ctx = Context(0)
+    ctx.set_conv_waves8(bool(a.waves8))
     if a.scratch_mib:
         ctx.set_conv_scratch(torch.empty(a.scratch_mib << 20, dtype=torch.uint8, device='cuda'))
     seen = {}
