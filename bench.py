@@ -359,17 +359,18 @@ def rccl_world1_rehearsal(eng, x, y, steps=10):
         dist.init_process_group('nccl', store=dist.HashStore(), rank=0, world_size=1, device_id=eng.dev)
         tr = DataParallelTrainer(eng, world_size=1, rank=0, force_bucket_path=True)
         ms = timed(lambda: tr.train_on_batch(x, y, **HPS))
-        tr.time_comm = True                     # a second pass brackets every collective with events on the comm stream
-        tr.comm_ms()
-        for _ in range(3):
-            tr.train_on_batch(x, y, **HPS)
-        n_coll = len(tr._comm_events) // 3
-        ar = tr.comm_ms() / 3
-        tr.time_comm = False
+        tr_main = DataParallelTrainer(eng, world_size=1, rank=0, force_bucket_path=True, comm_mode='main')
+        main_ms = timed(lambda: tr_main.train_on_batch(x, y, **HPS))
+        n_before = tr.collectives_launched
+        tr.train_on_batch(x, y, **HPS)
+        n_coll = tr.collectives_launched - n_before
+        torch.cuda.synchronize()
+        ar = tr.allreduce_ms()                  # the same collectives back to back, nothing overlapping them
         out = dict(rccl_ranks=dist.get_world_size(), backend=dist.get_backend(), bucket_mib=tr.bucket_bytes >> 20,
-                   gradient_mb=round(eng.n_params * 4 / 1e6, 2), collectives_per_step=n_coll + 1, allreduce_ms=round(ar, 3),
-                   ms_per_step=round(ms, 3), plain_ms_per_step_same_loop=round(plain_ms, 3), steps=steps,
-                   note='world-size-1 nccl group on this GPU: bucketed all_reduce calls on the comm stream overlapped with backward')
+                   gradient_mb=round(eng.n_params * 4 / 1e6, 2), collectives_per_step=n_coll, allreduce_ms=round(ar, 3), comm_mode=tr.comm_mode,
+                   ms_per_step=round(ms, 3), blocking_on_compute_stream_ms_per_step=round(main_ms, 3),
+                   plain_ms_per_step_same_loop=round(plain_ms, 3), steps=steps,
+                   note='world-size-1 nccl group on this GPU: bucketed all_reduce calls (async, on the group\'s own stream) overlapped with backward')
         dist.destroy_process_group()
         return out
     except Exception as e:      # the headline number must not depend on this rehearsal
@@ -513,24 +514,35 @@ def main():
     multi = None
     if world > 1:
         k = max(3, min(args.steps, 10))
-        trainer.time_comm = True
-        trainer.comm_ms()
-        for _ in range(k):
+        for _ in range(2):
             step()
-        allreduce_ms = trainer.comm_ms() / k
-        trainer.time_comm = False
+        torch.cuda.synchronize()
+        allreduce_ms = trainer.allreduce_ms()        # one step's collectives back to back, nothing overlapping them
         torch.cuda.synchronize(); trainer.barrier()
         t1 = time.perf_counter()
         for _ in range(k):
             eng.train_on_batch(x, y, **HPS)          # the same step without any collective (replicas diverge in rounding only;
         torch.cuda.synchronize()                     # nothing is measured after this block that depends on the weights)
         compute_ms = (time.perf_counter() - t1) / k * 1e3
+        # the same data-parallel step with the collectives BLOCKING on the compute stream (no overlap, no cross-stream traffic):
+        # on one GPU that form is 2.5 ms per step cheaper than any overlapped one (parallel.DataParallelTrainer); which wins here?
+        alt = DataParallelTrainer(eng, world_size=world, rank=rank, comm_mode='main' if trainer.comm_mode != 'main' else 'pg')
+        for _ in range(3):
+            alt.train_on_batch(x, y, **HPS)
+        torch.cuda.synchronize(); trainer.barrier()
+        t2 = time.perf_counter()
+        for _ in range(k):
+            alt.train_on_batch(x, y, **HPS)
+        trainer.barrier(); torch.cuda.synchronize()
+        alt_ms = trainer.max_over_ranks((time.perf_counter() - t2) / k * 1e3)
         mine = dict(rank=rank, allreduce_ms=round(allreduce_ms, 3), compute_only_ms=round(compute_ms, 3),
                     exposed_comm_ms=round(dt / args.steps * 1e3 - compute_ms, 3))
         allr = [None] * world
         dist.all_gather_object(allr, mine)
-        multi = dict(rccl_ranks=dist.get_world_size(), backend=dist.get_backend(), bucket_mib=trainer.bucket_bytes >> 20,
-                     gradient_mb=round(eng.n_params * 4 / 1e6, 2), per_rank=allr)
+        multi = dict(rccl_ranks=dist.get_world_size(), backend=dist.get_backend(), bucket_mib=trainer.bucket_bytes >> 20, comm_mode=trainer.comm_mode,
+                     gradient_mb=round(eng.n_params * 4 / 1e6, 2), per_rank=allr,
+                     alt_comm_mode=alt.comm_mode, alt_ms_per_step=round(alt_ms, 3),
+                     alt_images_per_sec=round(world * B / (alt_ms * 1e-3), 2))
         for t in (eng.params, eng.state, eng.m, eng.v):
             dist.broadcast(t, 0)
         trainer.barrier()

@@ -5,7 +5,8 @@ the full model on its 40-image slice with PER-RANK BatchNorm statistics (= the r
 per-tower statistics), the loss is the mean over the merged batch, so the gradient is the mean of
 the per-rank gradients.  Gradients live in one flat fp32 vector; as the backward pass finishes a
 layer the C ABI reports its range (fv_bucket_fn) and ranges are coalesced into buckets of
->= bucket_bytes that are all-reduced on a side stream while backward continues.  xGMI is
+>= bucket_bytes that are all-reduced asynchronously (on the process group's own stream) while backward
+continues; the compute stream waits for them before Adam.  xGMI is
 point-to-point, so few large collectives beat many small ones: default bucket 32 MiB
 (162.56 MB of gradients -> 5-6 collectives per step).  Adam then runs redundantly on every rank
 (bit-identical weights, no broadcast).
@@ -58,25 +59,34 @@ class BucketReducer(object):
 
 
 class DataParallelTrainer(object):
-    def __init__(self, engine, world_size=None, rank=None, bucket_bytes=32 << 20, force_bucket_path=False):
+    def __init__(self, engine, world_size=None, rank=None, bucket_bytes=32 << 20, force_bucket_path=False, comm_mode=None):
         self.eng = engine
         self.world = int(world_size if world_size is not None else os.environ.get('WORLD_SIZE', 1))
         self.rank = int(rank if rank is not None else os.environ.get('RANK', 0))
         self.bucket_bytes = bucket_bytes
         self.comm = None
         self.reducer = None
-        self._comm_events = []
         self.bucketed = self.world > 1 or force_bucket_path  # force: exercise the stream/bucket path on 1 GPU
+        # Where the collectives run (FV_COMM_STREAM):
+        #   'pg'   (default) dist.all_reduce(async_op=True): the collective runs on the process group's OWN stream, ordered after the
+        #          compute stream's work so far by the backend, and the compute stream waits for all of them before Adam -- the
+        #          overlap with the rest of the backward pass without a second hop;
+        #   'side' a communication stream of this trainer (compute -> event -> comm stream -> blocking all_reduce -> backend stream
+        #          and back): the round-1/2 form; FV_COMM_PRIORITY sets its priority (-1 = high);
+        #   'main' blocking all_reduce on the compute stream (no overlap).
+        # Measured on one MI355X with a world-size-1 nccl group (no RCCL kernel runs there: the stream / event traffic alone;
+        # tools/dp_overhead2.py, plain step 53.9 ms on that box): 'pg' 56.8, 'side' 56.8 (66.3 at high priority, 61.7 with
+        # GPU_MAX_HW_QUEUES=8), 'main' 54.3 -- a fixed 2.7-2.9 ms per step for ANY collective that is not waited for at once,
+        # independent of the number of buckets (7, 4 or 2 collectives per step: 56.0-56.6).  Whether hiding the real all-reduce
+        # (about 1 ms for 162 MB over seven xGMI links, if RCCL reaches its usual bus bandwidth) is worth that on 8 GPUs is for
+        # the first multi-GPU run to say: bench.py times both 'pg' and 'main' there (multi_gpu.alt_main_ms_per_step).
+        self.comm_mode = comm_mode or os.environ.get('FV_COMM_STREAM', 'pg')
+        if self.comm_mode not in ('pg', 'side', 'main'):
+            raise ValueError("FV_COMM_STREAM must be 'pg', 'side' or 'main'")
+        self._works = []
+        self.collectives_launched = 0
         if self.bucketed:
-            # The collectives run on their own stream, concurrently with the rest of the backward pass.  A/B knobs (measured on one
-            # MI355X with a world-size-1 RCCL group, tools/dp_overhead2.py: default 56.4 ms per step against 53.4 plain --
-            # RCCL's kernels and the matrix kernels share the CUs --, FV_COMM_PRIORITY=-1 66.3, GPU_MAX_HW_QUEUES=8 61.7):
-            # FV_COMM_STREAM=main enqueues them on the compute stream instead (no concurrency: the all-reduce time is exposed,
-            # nothing else is slowed); FV_COMM_PRIORITY sets the stream priority (-1 = high).  Which wins on 8 GPUs is a
-            # measurement the first multi-GPU run has to make (bench.py reports exposed_comm_ms per rank).
-            if os.environ.get('FV_COMM_STREAM', 'side') == 'main':
-                self.comm = torch.cuda.current_stream(engine.dev)
-            else:
+            if self.comm_mode == 'side':
                 self.comm = torch.cuda.Stream(device=engine.dev, priority=int(os.environ.get('FV_COMM_PRIORITY', '0')))
             engine.ensure_optimizer()
             self.reducer = BucketReducer(engine.grads, self.world, bucket_bytes, self._launch)
@@ -101,32 +111,45 @@ class DataParallelTrainer(object):
             dist.broadcast(engine.params, 0)
             dist.broadcast(engine.state, 0)
 
-    # collective on the side stream, ordered after the compute stream's work so far
     def _launch(self, view):
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.eng.dev))
-        with torch.cuda.stream(self.comm):
-            self.comm.wait_event(ev)
-            view.mul_(self._weight)            # n_rank / n_total: SUM over ranks = gradient of the merged-batch mean
-            if self.collective:
-                t0 = None
-                if self.time_comm:
-                    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-                    t0.record(self.comm)
+        """One bucket: scale by n_rank / n_total (SUM over ranks = gradient of the merged-batch mean), all-reduce."""
+        if self.comm_mode == 'side':
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.eng.dev))
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(ev)
+                if self._weight != 1.0:
+                    view.mul_(self._weight)
+                if self.collective:
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM)
+                    self.collectives_launched += 1
+            return
+        if self._weight != 1.0:
+            view.mul_(self._weight)
+        if self.collective:
+            if self.comm_mode == 'pg':
+                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+            else:
                 dist.all_reduce(view, op=dist.ReduceOp.SUM)
-                if t0 is not None:
-                    t1.record(self.comm)
-                    self._comm_events.append((t0, t1))
+            self.collectives_launched += 1
 
-    time_comm = False        # bench.py: bracket every collective with events on the comm stream
     _weight = 1.0
 
-    def comm_ms(self):
-        """Sum of the all-reduce durations recorded since the last call (syncs the comm stream)."""
-        self.comm.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in self._comm_events)
-        self._comm_events = []
-        return ms
+    def allreduce_ms(self):
+        """Cost of one step's gradient + BN-state collectives when NOTHING overlaps them: the buckets of the last step are
+        all-reduced again back to back on the compute stream between two events (leaves the gradients scaled; call it after
+        the measurements that need them).  0 without a process group."""
+        if not (self.collective and self.bucketed and self.reducer.launched):
+            return 0.0
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(self.eng.dev)
+        e0.record()
+        for lo, hi in self.reducer.launched:
+            dist.all_reduce(self.eng.grads[lo:hi], op=dist.ReduceOp.SUM)
+        dist.all_reduce(self.eng.state, op=dist.ReduceOp.SUM)
+        self.eng.state.mul_(1.0 / self.world)
+        e1.record(); torch.cuda.synchronize(self.eng.dev)
+        return e0.elapsed_time(e1)
 
     def train_on_batch(self, x, y, lr, beta_1, beta_2, decay=0.0, weight=None):
         """weight: this rank's share n_rank / n_total of the merged batch (default 1 / world)."""
@@ -137,15 +160,28 @@ class DataParallelTrainer(object):
         self.reducer.reset()
         loss = eng.forward_backward(x, y, on_bucket=self.reducer.on_range)
         self.reducer.flush()
-        with torch.cuda.stream(self.comm):
-            # BN moving statistics: the reference's towers race on shared variables (undefined
-            # order); we keep ranks identical by averaging (parity unpinned)
-            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(eng.dev))
-            self.comm.wait_event(ev)
+        # BN moving statistics: the reference's towers race on shared variables (undefined order); we keep ranks identical
+        # by averaging (parity unpinned)
+        if self.comm_mode == 'side':
+            with torch.cuda.stream(self.comm):
+                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(eng.dev))
+                self.comm.wait_event(ev)
+                if self.collective:
+                    dist.all_reduce(eng.state, op=dist.ReduceOp.SUM)
+                    self.collectives_launched += 1
+                eng.state.mul_(1.0 / self.world)
+            torch.cuda.current_stream(eng.dev).wait_stream(self.comm)
+        else:
             if self.collective:
-                dist.all_reduce(eng.state, op=dist.ReduceOp.SUM)
+                if self.comm_mode == 'pg':
+                    self._works.append(dist.all_reduce(eng.state, op=dist.ReduceOp.SUM, async_op=True))
+                else:
+                    dist.all_reduce(eng.state, op=dist.ReduceOp.SUM)
+                self.collectives_launched += 1
+            for w in self._works:           # the compute stream waits for every collective of this step (no host wait with nccl)
+                w.wait()
+            self._works = []
             eng.state.mul_(1.0 / self.world)
-        torch.cuda.current_stream(eng.dev).wait_stream(self.comm)
         eng.adam_step(lr, beta_1, beta_2, decay)
         return loss
 

@@ -32,20 +32,19 @@ for mode in ('plain', 'rccl'):
         dist.init_process_group('nccl', store=dist.HashStore(), rank=0, world_size=1, device_id=eng.dev)
     tr = DataParallelTrainer(eng, world_size=1, rank=0, bucket_bytes=8 << 20, force_bucket_path=(mode == 'rccl'))
     assert tr.collective == (mode == 'rccl')
-    tr.time_comm = True
     loss1 = float(tr.train_on_batch(x, y, 1e-4, 0.99, 0.99).item())
     torch.cuda.synchronize()
     g1 = eng.grads.clone(); m1 = eng.m.clone()
     for _ in range(2):
         loss = tr.train_on_batch(x, y, 1e-4, 0.99, 0.99)
     torch.cuda.synchronize()
-    ncoll = len(tr._comm_events)
+    ncoll = tr.collectives_launched
     res.append((loss1, g1, m1, float(loss.item()), eng.state.clone(), ncoll))
     if mode == 'rccl':
         cover = sorted(tr.reducer.launched)
         assert cover[0][0] == 0 and cover[-1][1] == eng.n_params and len(cover) >= 5
         assert all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
-        assert ncoll == 3 * len(cover), (ncoll, len(cover))          # every bucket of every step went through all_reduce
+        assert ncoll == 3 * (len(cover) + 1), (ncoll, len(cover))    # every bucket of every step + the BN state went through all_reduce
         assert tr.max_over_ranks(1.5) == 1.5
         tr.barrier()
         dist.destroy_process_group()

@@ -1,4 +1,5 @@
-"""Per-step times of the RCCL bucket path when it is the FIRST bucket-path use in the process (as in bench.py's rehearsal)."""
+"""Per-step times of the bucket path with / without a world-size-1 RCCL group (FV_COMM_STREAM=pg|side|main selects where the
+collectives run, parallel.DataParallelTrainer)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.distributed as dist
@@ -23,6 +24,6 @@ if mode == 'rccl_after':        # trainer (and its comm stream) first, then the 
 else:
     if mode == 'rccl':
         dist.init_process_group('nccl', store=dist.HashStore(), rank=0, world_size=1, device_id=eng.dev)
-    tr = DataParallelTrainer(eng, world_size=1, rank=0, force_bucket_path=True)
+    tr = DataParallelTrainer(eng, world_size=1, rank=0, force_bucket_path=True, bucket_bytes=int(os.environ.get('FV_BUCKET_MIB', '32')) << 20)
 print('bucket %-5s' % mode, ' '.join('%.1f' % t for t in steps(lambda: tr.train_on_batch(x, y, **HPS), 16)), flush=True)
 print('plain again', ' '.join('%.1f' % t for t in steps(lambda: eng.train_on_batch(x, y, **HPS), 8)), flush=True)
