@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dev tool: build an experimental variant of libfv_hotpath.so with extra compiler flags, e.g.
-#   tools/build_variant.sh sameaddr -DFV_ABLATE_SAMEADDR
-#   FV_LIB_PATH=tools/_variants/libfv_sameaddr.so python tools/layer_bench.py
+#   tools/build_variant.sh myflag -DFV_MY_EXPERIMENT     (the FV_ABLATE_* macros of rounds 1-2 were removed from csrc/ in round 3)
+#   FV_LIB_PATH=tools/_variants/libfv_myflag.so python tools/layer_bench.py
 # (tools/_variants/ is git-ignored; the .so still travels to the GPU box.)
 set -e
 name=$1; shift
