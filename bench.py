@@ -203,7 +203,7 @@ def loader_bench(eng, trainer, B, S, steps):
     import numpy as np
     import torch
     from face_vijnana_yolov3_amd import data
-    from face_vijnana_yolov3_amd.face_detection import BatchFeeder, train_on_item
+    from face_vijnana_yolov3_amd.face_detection import BatchFeeder, run_pipelined
     with tempfile.TemporaryDirectory() as root:
         n_img = 2 * B
         rng = np.random.default_rng(0)
@@ -240,25 +240,20 @@ def loader_bench(eng, trainer, B, S, steps):
             loader_only_pillow = max(loader_only_pillow, loader_rate(pil))
             loader_only = max(loader_only, loader_rate(feeder))
         pil.close()
-        feeder.prefetch(0)
-        for k in range(2):                             # warm-up
-            item = feeder.take(); feeder.prefetch((k + 1) % len(seq))
-            train_on_item(eng, trainer, item, S, hps)
+        run_pipelined(eng, trainer, feeder, [k % len(seq) for k in range(3)], S, hps)          # warm-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for k in range(steps):
-            item = feeder.take(); feeder.prefetch((k + 1) % len(seq))
-            train_on_item(eng, trainer, item, S, hps)
+        run_pipelined(eng, trainer, feeder, [k % len(seq) for k in range(steps)], S, hps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        feeder.take(); feeder.close()
+        feeder.close()
     return dict(value=round(B * steps / dt, 2), unit='images/sec', ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
                 loader_only_images_per_sec=round(loader_only, 1), loader_only_pillow_images_per_sec=round(loader_only_pillow, 1),
                 loader_threads=threads,
                 path='%d synthetic UCCS-format JPEGs (768x1024 .. 720x1280): Huffman decoding on host threads (fv_jpeg_entropy_decode) '
                      '-> quantised coefficients in one pinned buffer -> H2D -> fv_jpeg_reconstruct_batch (IDCT, chroma upsampling, '
-                     'colour conversion on the device) -> fv_letterbox_batch -> fv_train_step + Adam; batch k+1 decoded while step k '
-                     'runs; loader_only_pillow = the same loader with the whole decode in Pillow on the host' % n_img)
+                     'colour conversion on the device) -> fv_letterbox_batch on a staging stream -> fv_train_step + Adam; batch k+2 decoded '
+                     'and batch k+1 staged while step k runs; loader_only_pillow = the same loader with the whole decode in Pillow on the host' % n_img)
 
 
 def test_loop_bench(device, S, n_img=64):

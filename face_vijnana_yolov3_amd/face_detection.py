@@ -155,22 +155,18 @@ class FaceDetector(object):
             order = rng.permutation(steps)  # Keras fit_generator shuffles batch order (shuffle=True)
             if self.rank == 0:
                 print('Epoch %d/%d' % (epoch + 1, hp['epochs']))
-            feeder.prefetch(int(order[0]))
-            for k in range(steps):
-                item = feeder.take()
-                if k + 1 < steps:
-                    feeder.prefetch(int(order[k + 1]))   # decode of batch k+1 overlaps step k
+            def after_step(k, loss, item):
                 if item is None:
                     if self.rank == 0:
                         print('%d/%d - skipped (fewer images than ranks)' % (k + 1, steps))
-                    continue
-                loss = train_on_item(self.model, trainer, item, self.image_size, hp)
+                    return
                 # Keras prints the loss of the MERGED batch at every step (verbose=1, fd.py:621-627); reading it is a host
                 # sync (and one small all-reduce when world > 1): hps['log_every'] = n prints every n-th step only
                 if ((k + 1) % log_every == 0 and DEBUG) or k + 1 == steps:
                     lv = trainer.merged_loss(loss, item[2])          # collective: every rank calls it
                     if self.rank == 0:
                         print('%d/%d - loss: %.4f' % (k + 1, steps, lv))
+            run_pipelined(self.model, trainer, feeder, [int(i) for i in order], self.image_size, hp, after_step)
         feeder.close()
         if self.rank == 0:
             print('Save the model.')
@@ -464,14 +460,88 @@ class BatchFeeder(object):
 
 
 def train_on_item(engine, trainer, item, image_size, hp):
-    """One optimisation step on what BatchFeeder.load returned: H2D copy, device letterbox, fv_train_step
-    (+ gradient all-reduce when world > 1), Adam."""
+    """One optimisation step on what BatchFeeder.load returned, everything on the compute stream: H2D copy, device JPEG
+    reconstruction / letterbox, fv_train_step (+ gradient all-reduce when world > 1), Adam.  run_pipelined() is the overlapped form."""
     packed, y, weight, (feeder, slot) = item
     x, _ = letterbox_batch_device(engine.ctx, None, image_size, engine.dev, packed=packed)
     if slot is not None:
         feeder.copied(slot)
     yd = [t.to(engine.dev, non_blocking=True) for t in y] if isinstance(y, (tuple, list)) else y.to(engine.dev, non_blocking=True)
     return trainer.train_on_batch(x, yd, hp['lr'], hp['beta_1'], hp['beta_2'], hp.get('decay', 0.0), weight=weight)
+
+
+class DeviceStager(object):
+    """The device half of the input path -- H2D copy of the batch (89 MB of JPEG coefficients or raw pixels at batch 40: 2-4 ms
+    of PCIe time), fv_jpeg_reconstruct_batch, fv_letterbox_batch, targets -- on its OWN stream, so that batch k+1 is staged while
+    step k computes instead of in front of step k+1 (measured: 56.7 -> see DESIGN 6 ms per step with the loader in the loop)."""
+
+    def __init__(self, engine, image_size):
+        import torch
+        self.eng, self.S = engine, image_size
+        self.stream = torch.cuda.Stream(device=engine.dev)
+
+    def stage(self, item):
+        import torch
+        if item is None:
+            return None
+        packed, y, weight, (feeder, slot) = item
+        main = torch.cuda.current_stream(self.eng.dev)
+        with torch.cuda.stream(self.stream):
+            self.eng.ctx.set_stream(self.stream.cuda_stream)      # the library's launches of this block go to the staging stream
+            try:
+                x, _ = letterbox_batch_device(self.eng.ctx, None, self.S, self.eng.dev, packed=packed)
+            finally:
+                self.eng.ctx.set_stream(main.cuda_stream)
+            if slot is not None:
+                feeder.copied(slot)                               # event on the staging stream: the pinned buffer is free after it
+            yd = [t.to(self.eng.dev, non_blocking=True) for t in y] if isinstance(y, (tuple, list)) else y.to(self.eng.dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return x, yd, weight, ev
+
+    def use(self, staged):
+        """Make the compute stream wait for the staged batch; -> (x, targets, weight)."""
+        import torch
+        x, yd, weight, ev = staged
+        main = torch.cuda.current_stream(self.eng.dev)
+        main.wait_event(ev)
+        for t in [x] + (list(yd) if isinstance(yd, (tuple, list)) else [yd]):
+            t.record_stream(main)                                 # allocated on the staging stream, consumed on the compute stream
+        return x, yd, weight
+
+
+def run_pipelined(engine, trainer, feeder, indices, image_size, hp, after_step=None):
+    """One optimisation step per batch index in `indices`, the input side pipelined two deep: while step k computes, the host
+    threads decode batch k+2 (BatchFeeder) and the staging stream copies, reconstructs and letterboxes batch k+1 (DeviceStager).
+    after_step(k, loss, item) is called one step late -- once step k+1 is in the queue -- so that reading the loss (a host sync)
+    never leaves the GPU idle (item None: batch skipped on all ranks)."""
+    n = len(indices)
+    if n == 0:
+        return
+    stager = DeviceStager(engine, image_size)
+    feeder.prefetch(indices[0])
+    item = feeder.take()
+    if n > 1:
+        feeder.prefetch(indices[1])
+    staged = stager.stage(item)
+    lagged = None                                                 # (k, loss copy, item) of the previous step, reported one step late
+    for k in range(n):
+        cur, item_k, loss = staged, item, None
+        if cur is not None:
+            x, yd, weight = stager.use(cur)
+            loss = trainer.train_on_batch(x, yd, hp['lr'], hp['beta_1'], hp['beta_2'], hp.get('decay', 0.0), weight=weight)
+            loss = loss.clone()                                   # the engine reuses its loss buffer: keep this step's value
+        if k + 1 < n:
+            item = feeder.take()                                  # the host waits for the decode of k+1 while the GPU runs step k
+            if k + 2 < n:
+                feeder.prefetch(indices[k + 2])
+            staged = stager.stage(item)
+        # reading a loss is a host sync: report step k-1 now that step k is in the queue, so the GPU never waits for the host
+        if after_step is not None and lagged is not None:
+            after_step(*lagged)
+        lagged = (k, loss, item_k)
+    if after_step is not None and lagged is not None:
+        after_step(*lagged)
 
 
 def _font():
