@@ -108,3 +108,35 @@ def test_training_feeder_through_coefficients_equals_pillow(tmp_path):
         xs.append((x.clone(), y.clone()))
         f.close()
     assert torch.equal(xs[0][0], xs[1][0]) and torch.equal(xs[0][1], xs[1][1])
+
+
+def test_pipelined_input_path_equals_the_serial_one(tmp_path):
+    """run_pipelined (batch k+1 staged on its own stream while step k computes, losses reported one step late) against
+    train_on_item (everything on the compute stream): same batches in the same order -> the same losses and, up to the float-atomic
+    order inside dW, the same parameters after three Adam steps."""
+    from face_vijnana_yolov3_amd import data
+    from face_vijnana_yolov3_amd.engine import Engine
+    from face_vijnana_yolov3_amd.face_detection import BatchFeeder, run_pipelined, train_on_item
+    from face_vijnana_yolov3_amd.parallel import DataParallelTrainer
+    root = str(tmp_path)
+    data.make_synthetic_uccs(root, n_images=6, seed=6)
+    hp = {'batch_size': 2, 'step': 1, 'lr': 1e-4, 'beta_1': 0.99, 'beta_2': 0.99, 'decay': 0.0}
+    res = []
+    for pipelined in (False, True):
+        eng = Engine(0); eng.init_synthetic(7)
+        tr = DataParallelTrainer(eng, world_size=1, rank=0)
+        seq = data.TrainingSequence(root, dict(hp), {'image_size': 96, 'bb_info_c_size': 6})
+        f = BatchFeeder(seq, 1, 0, 2)
+        losses = []
+        if pipelined:
+            run_pipelined(eng, tr, f, [0, 1, 2], 96, hp, lambda k, loss, item: losses.append((k, float(loss.item()))))
+        else:
+            for k in range(3):
+                losses.append((k, float(train_on_item(eng, tr, f.load(k), 96, hp).item())))
+        torch.cuda.synchronize()
+        f.close()
+        res.append((losses, eng.params.clone()))
+    assert [k for k, _ in res[1][0]] == [0, 1, 2]
+    for i, ((_, a), (_, b)) in enumerate(zip(res[0][0], res[1][0])):
+        assert abs(a - b) <= (1e-6 if i == 0 else 5e-3) * abs(a), (i, a, b)    # later steps: Adam amplifies the atomic-order noise
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=0, atol=7e-4)      # three Adam steps of lr 1e-4
