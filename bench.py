@@ -352,8 +352,13 @@ def rccl_world1_rehearsal(eng, x, y, steps=10):
             return (time.perf_counter() - t0) / steps * 1e3
         plain_ms = timed(lambda: eng.train_on_batch(x, y, **HPS))           # the same loop without the DP machinery, for comparison
         dist.init_process_group('nccl', store=dist.HashStore(), rank=0, world_size=1, device_id=eng.dev)
-        tr = DataParallelTrainer(eng, world_size=1, rank=0, force_bucket_path=True)
+        tr = DataParallelTrainer(eng, world_size=1, rank=0, force_bucket_path=True, comm_mode='pg')
         ms = timed(lambda: tr.train_on_batch(x, y, **HPS))
+        tr_auto = DataParallelTrainer(eng, world_size=1, rank=0, force_bucket_path=True, comm_mode='auto')
+        for _ in range(32):                     # the default mode: measures 'pg' and 'main' over its first steps, keeps the faster
+            if not tr_auto.calibrating:
+                break
+            tr_auto.train_on_batch(x, y, **HPS)
         tr_main = DataParallelTrainer(eng, world_size=1, rank=0, force_bucket_path=True, comm_mode='main')
         main_ms = timed(lambda: tr_main.train_on_batch(x, y, **HPS))
         n_before = tr.collectives_launched
@@ -363,7 +368,7 @@ def rccl_world1_rehearsal(eng, x, y, steps=10):
         ar = tr.allreduce_ms()                  # the same collectives back to back, nothing overlapping them
         out = dict(rccl_ranks=dist.get_world_size(), backend=dist.get_backend(), bucket_mib=tr.bucket_bytes >> 20,
                    gradient_mb=round(eng.n_params * 4 / 1e6, 2), collectives_per_step=n_coll, allreduce_ms=round(ar, 3), comm_mode=tr.comm_mode,
-                   ms_per_step=round(ms, 3), blocking_on_compute_stream_ms_per_step=round(main_ms, 3),
+                   auto=tr_auto.auto_report, ms_per_step=round(ms, 3), blocking_on_compute_stream_ms_per_step=round(main_ms, 3),
                    plain_ms_per_step_same_loop=round(plain_ms, 3), steps=steps,
                    note='world-size-1 nccl group on this GPU: bucketed all_reduce calls (async, on the group\'s own stream) overlapped with backward')
         dist.destroy_process_group()
@@ -402,26 +407,17 @@ def self_launch(args):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks as FRESH child processes through
     torch.distributed.run (one process per GPU, RCCL rendezvous on 127.0.0.1) BEFORE this process makes any GPU call,
     relay rank 0's JSON line on stdout (everything else goes to stderr) and return the launcher's exit code."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
+    from face_vijnana_yolov3_amd.parallel import launch_ranks
     argv = [a for a in sys.argv[1:] if a != '--spawn']
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + argv
-    env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # this pool's driver only supports dmabuf IPC (RCCL needs it)
-    env['FV_BENCH_SELF_LAUNCHED'] = '1'
-    print('bench.py: starting %d ranks: %s' % (args.gpus, ' '.join(cmd)), file=sys.stderr, flush=True)
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
-    got = False
-    for line in proc.stdout:
+    got = []
+
+    def relay(line):
         if line.startswith('{"metric"'):
-            sys.stdout.write(line); sys.stdout.flush(); got = True
+            sys.stdout.write(line); sys.stdout.flush(); got.append(1)
         else:
             sys.stderr.write(line); sys.stderr.flush()
-    rc = proc.wait()
+
+    rc = launch_ranks(args.gpus, [os.path.abspath(__file__)] + argv, {'FV_BENCH_SELF_LAUNCHED': '1'}, relay)
     if rc == 0 and not got:
         print('bench.py: the ranks exited 0 without printing a result line', file=sys.stderr)
         rc = 1
@@ -487,6 +483,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    for _ in range(32):                             # comm_mode 'auto' (N > 1): the choice is made before the timed region
+        if not trainer.calibrating:
+            break
+        step()
     # per-step marks for the median: one event record per step on the launch stream (no host sync inside the region)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     trainer.barrier()
@@ -535,7 +535,7 @@ def main():
         allr = [None] * world
         dist.all_gather_object(allr, mine)
         multi = dict(rccl_ranks=dist.get_world_size(), backend=dist.get_backend(), bucket_mib=trainer.bucket_bytes >> 20, comm_mode=trainer.comm_mode,
-                     gradient_mb=round(eng.n_params * 4 / 1e6, 2), per_rank=allr,
+                     auto=trainer.auto_report, gradient_mb=round(eng.n_params * 4 / 1e6, 2), per_rank=allr,
                      alt_comm_mode=alt.comm_mode, alt_ms_per_step=round(alt_ms, 3),
                      alt_images_per_sec=round(world * B / (alt_ms * 1e-3), 2))
         for t in (eng.params, eng.state, eng.m, eng.v):

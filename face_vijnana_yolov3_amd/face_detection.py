@@ -9,8 +9,9 @@ ratios.csv, the model files).  Differences, all documented in DESIGN.md:
     main interpreter): the reference's `model.load_weights` / h5py read them and the reference's face_detector.h5 /
     yolov3_base.h5 load here; there is no `model_config`, so Keras' `load_model` does not take them
   * the grid is image_size/32 (the reference hard-codes 13, consistent only at 416)
-  * multi_gpu=True means one process per GPU (torchrun) with RCCL all-reduce instead of
-    keras.utils.multi_gpu_model towers; launched as a single process it trains on one GPU
+  * multi_gpu=True means one process per GPU with RCCL all-reduce instead of keras.utils.multi_gpu_model towers: main()
+    starts num_gpus ranks itself (parallel.launch_ranks -> torch.distributed.run); a FaceDetector constructed directly in a
+    process without WORLD_SIZE trains on one GPU
   * evaluate() tolerates images without ground-truth rows and a missing arial.ttf
   * evaluate()/test() read ahead and run the network on batches of hps['eval_batch_size'] images (default 16; the
     reference's loop is batch 1, fd.py:632-883) -- same rows in the same order
@@ -473,7 +474,7 @@ def train_on_item(engine, trainer, item, image_size, hp):
 class DeviceStager(object):
     """The device half of the input path -- H2D copy of the batch (89 MB of JPEG coefficients or raw pixels at batch 40: 2-4 ms
     of PCIe time), fv_jpeg_reconstruct_batch, fv_letterbox_batch, targets -- on its OWN stream, so that batch k+1 is staged while
-    step k computes instead of in front of step k+1 (measured: 56.7 -> see DESIGN 6 ms per step with the loader in the loop)."""
+    step k computes instead of in front of step k+1 (measured with the loader in the loop: 56.7 -> 55.3-56.0 ms per step)."""
 
     def __init__(self, engine, image_size):
         import torch
@@ -578,6 +579,12 @@ def main():
         conf = json.load(f)['fd_conf']
     if conf['mode'] not in ('train', 'evaluate', 'test'):
         return
+    n = int(conf.get('num_gpus', 1)) if conf.get('multi_gpu') else 1
+    if n > 1 and 'WORLD_SIZE' not in os.environ:
+        # multi_gpu_model(model, gpus=num_gpus) (fd.py:358-371) is one process driving num_gpus towers; here it is one process
+        # per GPU, started from this one BEFORE it makes any GPU call -- the reference's command line stays what it was
+        from .parallel import launch_ranks
+        raise SystemExit(launch_ranks(n, ['-m', 'face_vijnana_yolov3_amd.face_detection']))
     fd = FaceDetector(conf)
     ts = time.time()
     getattr(fd, conf['mode'])()

@@ -80,9 +80,18 @@ class DataParallelTrainer(object):
         # independent of the number of buckets (7, 4 or 2 collectives per step: 56.0-56.6).  Whether hiding the real all-reduce
         # (about 1 ms for 162 MB over seven xGMI links, if RCCL reaches its usual bus bandwidth) is worth that on 8 GPUs is for
         # the first multi-GPU run to say: bench.py times both 'pg' and 'main' there (multi_gpu.alt_main_ms_per_step).
-        self.comm_mode = comm_mode or os.environ.get('FV_COMM_STREAM', 'pg')
-        if self.comm_mode not in ('pg', 'side', 'main'):
-            raise ValueError("FV_COMM_STREAM must be 'pg', 'side' or 'main'")
+        #   'auto' (default) the first AUTO_WARM + 2 * AUTO_STEPS + 1 optimisation steps time 'pg' and then 'main' (max over ranks,
+        #          so every rank decides alike) and the faster one is kept -- self.auto_report says what was measured.
+        self.comm_mode = comm_mode or os.environ.get('FV_COMM_STREAM', 'auto')
+        if self.comm_mode not in ('pg', 'side', 'main', 'auto'):
+            raise ValueError("FV_COMM_STREAM must be 'auto', 'pg', 'side' or 'main'")
+        self.auto_report = None
+        self._auto_k = None
+        if self.comm_mode == 'auto':
+            self.comm_mode = 'pg'
+            # resolved in train_on_batch (needs a process group to be worth measuring); a trainer without the bucket path has
+            # no collectives and nothing to decide
+            self._auto_k = 0 if self.bucketed else None
         self._works = []
         self.collectives_launched = 0
         if self.bucketed:
@@ -134,6 +143,39 @@ class DataParallelTrainer(object):
             self.collectives_launched += 1
 
     _weight = 1.0
+    AUTO_WARM, AUTO_STEPS = 3, 4
+
+    def _auto_tick(self):
+        """comm_mode 'auto': called at the top of every step until decided.  Steps [0, W) warm up in 'pg', [W, W+S) time 'pg',
+        step W+S warms 'main', [W+S+1, W+2S+1) time 'main'; at step W+2S+1 the two times are max-reduced over the ranks and the
+        faster mode is kept.  Three host synchronisations in all; every step of the calibration is an ordinary training step."""
+        import time
+        W, S, k = self.AUTO_WARM, self.AUTO_STEPS, self._auto_k
+        if not self.collective:                  # nothing to overlap without a group
+            self.comm_mode, self._auto_k = 'main', None
+            return
+        if k in (W, W + S, W + S + 1, W + 2 * S + 1):
+            torch.cuda.synchronize(self.eng.dev)
+            now = time.perf_counter()
+            if k == W + S:
+                self._auto_pg = (now - self._auto_t0) / S * 1e3
+                self.comm_mode = 'main'
+            elif k == W + 2 * S + 1:
+                t = torch.tensor([self._auto_pg, (now - self._auto_t0) / S * 1e3], dtype=torch.float64, device=self.eng.dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                pg_ms, main_ms = (float(v) for v in t.cpu())
+                self.comm_mode = 'pg' if pg_ms < main_ms else 'main'
+                self.auto_report = dict(pg_ms_per_step=round(pg_ms, 3), main_ms_per_step=round(main_ms, 3), chosen=self.comm_mode,
+                                        steps_each=S)
+                self._auto_k = None
+                return
+            self._auto_t0 = now
+        self._auto_k = k + 1
+
+    @property
+    def calibrating(self):
+        """True while comm_mode 'auto' is still measuring (bench.py keeps those steps out of its timed region)."""
+        return self._auto_k is not None
 
     def allreduce_ms(self):
         """Cost of one step's gradient + BN-state collectives when NOTHING overlaps them: the buckets of the last step are
@@ -156,6 +198,8 @@ class DataParallelTrainer(object):
         eng = self.eng
         if not self.bucketed:
             return eng.train_on_batch(x, y, lr, beta_1, beta_2, decay)
+        if self._auto_k is not None:
+            self._auto_tick()
         self._weight = float(weight) if weight is not None else 1.0 / self.world
         self.reducer.reset()
         loss = eng.forward_backward(x, y, on_bucket=self.reducer.on_range)
@@ -210,6 +254,32 @@ class DataParallelTrainer(object):
             dist.barrier()
             if self._own_group:
                 dist.destroy_process_group()
+
+
+def launch_ranks(n, target, extra_env=None, on_stdout_line=None):
+    """Start n ranks (one process per GPU, rendezvous on 127.0.0.1 over a free port) as FRESH children through
+    torch.distributed.run and return the launcher's exit code.  `target` is what follows the launcher's own options:
+    ['script.py', args...] or ['-m', 'package.module', args...].  Must be called before this process makes any GPU call (the
+    children own the devices).  With on_stdout_line the children's stdout is piped and every line handed to it; otherwise they
+    inherit this process's descriptors."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(int(n)), '--master-addr', '127.0.0.1',
+           '--master-port', str(port)] + list(target)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # this pool's driver only supports dmabuf IPC (RCCL needs it)
+    env.update(extra_env or {})
+    print('starting %d ranks: %s' % (n, ' '.join(cmd)), file=sys.stderr, flush=True)
+    if on_stdout_line is None:
+        return subprocess.call(cmd, env=env)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+    for line in proc.stdout:
+        on_stdout_line(line)
+    return proc.wait()
 
 
 def slice_batch(n, world_size, rank):

@@ -37,3 +37,30 @@ def test_spawn_flag_goes_through_the_launcher_at_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip())
     assert d['n_gpus'] == 1 and d['value'] == 1.0
+
+
+def test_face_detection_main_starts_num_gpus_ranks(tmp_path, monkeypatch):
+    """fd_conf.multi_gpu + num_gpus > 1 (fd.py:358-371): main() starts the ranks itself and never constructs a FaceDetector in
+    the parent; inside a rank (WORLD_SIZE set) it does not launch again."""
+    from face_vijnana_yolov3_amd import face_detection, parallel
+    monkeypatch.chdir(tmp_path)
+    conf = {'mode': 'train', 'multi_gpu': True, 'num_gpus': 4}
+    json.dump({'fd_conf': conf, 'fi_conf': {}}, open('face_vijnana_yolov3.json', 'w'))
+    calls = []
+    monkeypatch.setattr(parallel, 'launch_ranks', lambda n, target, *a, **k: calls.append((n, list(target))) or 7)
+    monkeypatch.setattr(face_detection, 'FaceDetector', lambda conf: (_ for _ in ()).throw(AssertionError('parent built a detector')))
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    try:
+        face_detection.main()
+        raise AssertionError('main() returned')
+    except SystemExit as e:
+        assert e.code == 7
+    assert calls == [(4, ['-m', 'face_vijnana_yolov3_amd.face_detection'])]
+    # a rank: builds the detector (here: the stand-in raises), does not launch
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    try:
+        face_detection.main()
+        raise AssertionError('no detector built')
+    except AssertionError as e:
+        assert 'parent built a detector' in str(e)
+    assert len(calls) == 1

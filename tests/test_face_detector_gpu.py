@@ -180,3 +180,29 @@ def test_csv_rows_match_the_reference_test_golden(tmp_path, monkeypatch, golden_
     pos[0] = 0
     fd.evaluate()
     assert open(os.path.join(root, 'solution_eval.csv')).read().splitlines() == text
+
+
+def test_main_with_multi_gpu_starts_its_ranks_and_trains(tmp_path):
+    """The reference's command line with fd_conf.multi_gpu / num_gpus = 2 (fd.py:358-371, 612-619): main() starts two ranks itself
+    (two processes on this box's one GPU; gloo as the transport because RCCL refuses two ranks on one device), they train the
+    sharded batches, rank 0 writes the model file (bit-identical replicas: tests/test_dp_rehearsal_gpu.py)."""
+    import subprocess
+    import sys
+    from face_vijnana_yolov3_amd import data, hdf5_lite
+    root = str(tmp_path / 'train'); os.makedirs(root)
+    data.make_synthetic_uccs(root, n_images=6, seed=3, csv_name='training.csv')
+    conf = _conf(root, 'train', image_size=96, batch=3)
+    conf['multi_gpu'] = True; conf['num_gpus'] = 2
+    json.dump({'fd_conf': conf, 'fi_conf': {}}, open(tmp_path / 'face_vijnana_yolov3.json', 'w'))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(FV_DIST_BACKEND='gloo', PYTHONPATH=repo + os.pathsep + env.get('PYTHONPATH', ''))
+    r = subprocess.run([sys.executable, '-m', 'face_vijnana_yolov3_amd.face_detection'], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'starting 2 ranks' in r.stderr
+    assert r.stdout.count('Save the model.') == 1 and 'Epoch 1/1' in r.stdout
+    assert hdf5_lite.is_hdf5(str(tmp_path / 'face_detector.h5'))
+    ds, _ = hdf5_lite.read_hdf5(str(tmp_path / 'face_detector.h5'))
+    assert int(np.asarray(ds['/fv/iterations']).reshape(-1)[0]) == 2          # 6 images, merged batch 3 (2 + 1 per rank), one epoch
+    assert all(np.isfinite(v).all() for k, v in ds.items() if v.dtype.kind == 'f')

@@ -46,6 +46,16 @@ for mode in ('plain', 'rccl'):
         assert all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
         assert ncoll == 3 * (len(cover) + 1), (ncoll, len(cover))    # every bucket of every step + the BN state went through all_reduce
         assert tr.max_over_ranks(1.5) == 1.5
+        # the default comm mode is 'auto': overlapped ('pg') while it calibrates, then 'pg' and 'main' timed and one kept
+        assert tr.calibrating and tr.comm_mode == 'pg'
+        n = 3
+        while tr.calibrating:
+            tr.train_on_batch(x, y, 1e-4, 0.99, 0.99); n += 1
+        rep = tr.auto_report
+        assert n == tr.AUTO_WARM + 2 * tr.AUTO_STEPS + 2 and rep['chosen'] == tr.comm_mode and rep['chosen'] in ('pg', 'main'), (n, rep)
+        assert rep['pg_ms_per_step'] > 0 and rep['main_ms_per_step'] > 0
+        assert tr.collectives_launched == n * (len(cover) + 1)
+        assert torch.isfinite(eng.params).all()
         tr.barrier()
         dist.destroy_process_group()
 # first step: same loss, same (all-reduced) gradient and first Adam moment up to the float-atomic order inside dW
@@ -81,3 +91,4 @@ def test_bench_through_its_own_launcher_on_one_gpu():
     assert d['n_gpus'] == 1 and d['value'] > 0 and d['median_ms_per_step'] > 0
     assert d['multi_gpu'] and d['multi_gpu'].get('rccl_ranks') == 1 and d['multi_gpu']['backend'] == 'nccl', d['multi_gpu']
     assert d['multi_gpu']['collectives_per_step'] >= 5
+    assert d['multi_gpu']['auto']['chosen'] in ('pg', 'main')
