@@ -67,8 +67,8 @@ class FaceDetector(object):
         self.cell_image_size = self.image_size // self.grid
         self.rank = int(os.environ.get('RANK', 0))
         self.world = int(os.environ.get('WORLD_SIZE', 1)) if conf.get('multi_gpu') else 1
-        if device is None:
-            device = int(os.environ.get('LOCAL_RANK', 0))
+        if device is None:           # FV_DEVICE: several ranks on ONE device, to rehearse N > 1 on a one-GPU box (gloo transport)
+            device = int(os.environ.get('FV_DEVICE', os.environ.get('LOCAL_RANK', 0)))
         self.three_scale = self.nn_arch.get('head', 'single') == 'three_scale'
         if self.nn_arch.get('head', 'single') not in ('single', 'three_scale'):
             raise ValueError("nn_arch.head must be 'single' or 'three_scale'")

@@ -196,7 +196,7 @@ def test_main_with_multi_gpu_starts_its_ranks_and_trains(tmp_path):
     json.dump({'fd_conf': conf, 'fi_conf': {}}, open(tmp_path / 'face_vijnana_yolov3.json', 'w'))
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    env.update(FV_DIST_BACKEND='gloo', PYTHONPATH=repo + os.pathsep + env.get('PYTHONPATH', ''))
+    env.update(FV_DIST_BACKEND='gloo', FV_DEVICE='0', PYTHONPATH=repo + os.pathsep + env.get('PYTHONPATH', ''))
     r = subprocess.run([sys.executable, '-m', 'face_vijnana_yolov3_amd.face_detection'], cwd=str(tmp_path), env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
