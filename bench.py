@@ -67,8 +67,9 @@ def parse():
     ap.add_argument('--no-rccl-rehearsal', action='store_true', help='N=1: skip the world-size-1 RCCL group rehearsal')
     ap.add_argument('--no-loader', action='store_true', help='skip the loader-inclusive measurement')
     ap.add_argument('--no-three-scale', action='store_true', help='skip the three-scale training measurement')
-    ap.add_argument('--loader-steps', type=int, default=6)
+    ap.add_argument('--loader-steps', type=int, default=16)
     ap.add_argument('--child-three-scale', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--child-loader', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -240,20 +241,57 @@ def loader_bench(eng, trainer, B, S, steps):
             loader_only_pillow = max(loader_only_pillow, loader_rate(pil))
             loader_only = max(loader_only, loader_rate(feeder))
         pil.close()
-        run_pipelined(eng, trainer, feeder, [k % len(seq) for k in range(3)], S, hps)          # warm-up
+        # ONE pipelined run of 4 + steps batches; steady state = from the end of step 3 to the end of the last step, between two
+        # events on the compute stream (after_step(k) is called once step k + 1 is in the queue).  The run's first batch is
+        # decoded and staged with nothing to overlap it (~30 ms of pipeline fill, once per epoch): reported beside, not inside.
+        n = 4 + steps
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+        def after_step(k, loss, item):
+            if k == 2:
+                ev0.record()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_pipelined(eng, trainer, feeder, [k % len(seq) for k in range(steps)], S, hps)
+        run_pipelined(eng, trainer, feeder, [k % len(seq) for k in range(n)], S, hps, after_step)
+        ev1.record()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        whole = (time.perf_counter() - t0) / n * 1e3
+        dt = ev0.elapsed_time(ev1) * 1e-3
         feeder.close()
     return dict(value=round(B * steps / dt, 2), unit='images/sec', ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
+                ms_per_step_with_pipeline_fill=round(whole, 3),
                 loader_only_images_per_sec=round(loader_only, 1), loader_only_pillow_images_per_sec=round(loader_only_pillow, 1),
                 loader_threads=threads,
                 path='%d synthetic UCCS-format JPEGs (768x1024 .. 720x1280): Huffman decoding on host threads (fv_jpeg_entropy_decode) '
                      '-> quantised coefficients in one pinned buffer -> H2D -> fv_jpeg_reconstruct_batch (IDCT, chroma upsampling, '
                      'colour conversion on the device) -> fv_letterbox_batch on a staging stream -> fv_train_step + Adam; batch k+2 decoded '
                      'and batch k+1 staged while step k runs; loader_only_pillow = the same loader with the whole decode in Pillow on the host' % n_img)
+
+
+def loader_child(args):
+    """`--child-loader`: the loader-inclusive section in a process of its own (the same late-in-process slowdown as the three-scale
+    section: 55.3-56.0 ms per step measured after the detect / test() sections of the parent against 53.3 in a fresh process,
+    tools/pipeline_probe.py); also times the resident-input step in THIS process, so the two are comparable."""
+    import torch
+    from face_vijnana_yolov3_amd import data
+    from face_vijnana_yolov3_amd.engine import Engine
+    from face_vijnana_yolov3_amd.parallel import DataParallelTrainer
+    B, S = args.batch, args.image_size
+    eng = Engine(0)
+    eng.init_synthetic(seed=7)
+    trainer = DataParallelTrainer(eng, world_size=1, rank=0)
+    x = torch.rand((B, S, S, 3), generator=torch.Generator().manual_seed(1234)).cuda()
+    y = torch.from_numpy(data.synth_gt_batch(B, S, seed=1234)).cuda()
+    for _ in range(8):
+        trainer.train_on_batch(x, y, **HPS)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.loader_steps):
+        trainer.train_on_batch(x, y, **HPS)
+    torch.cuda.synchronize()
+    resident = (time.perf_counter() - t0) / args.loader_steps * 1e3
+    out = loader_bench(eng, trainer, B, S, args.loader_steps)
+    out['resident_input_ms_per_step_same_process'] = round(resident, 3)
+    return out
 
 
 def test_loop_bench(device, S, n_img=64):
@@ -429,6 +467,9 @@ def main():
     if args.child_three_scale:                     # helper mode of the parent's three_scale_train section
         print(json.dumps(three_scale_bench(0, args.image_size, steps=5)), flush=True)
         return
+    if args.child_loader:                          # helper mode of the parent's loader_inclusive section
+        print(json.dumps(loader_child(args)), flush=True)
+        return
     if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.spawn):
         sys.exit(self_launch(args))              # nothing above touched the GPU: the children own the devices
     # Rank 0's JSON line is the ONLY thing on stdout: C libraries write to fd 1 too (RCCL prints its version banner there at
@@ -573,7 +614,11 @@ def main():
             detect['test_loop'] = test_loop_bench(local_rank, S)
         loader = None
         if world == 1 and not args.no_loader:
-            loader = loader_bench(eng, trainer, B, S, args.loader_steps)
+            import subprocess                # in a fresh child process, like the three-scale section below (loader_child)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--child-loader', '--image-size', str(S), '--batch', str(B),
+                                '--loader-steps', str(args.loader_steps)], capture_output=True, text=True, timeout=900)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"value"')]
+            loader = json.loads(line[-1]) if r.returncode == 0 and line else dict(error=(r.stderr or r.stdout)[-400:])
         three = None
         if world == 1 and not args.no_three_scale and not args.no_detect:
             # in a FRESH child process: measured in this one, after the other sections, the same step ran 41 instead of 31.6 ms
