@@ -294,10 +294,10 @@ def loader_child(args):
     return out
 
 
-def test_loop_bench(device, S, n_img=64):
+def test_loop_bench(device, S, n_img=128):
     """FaceDetector.test() end to end (fd.py:783-883: JPEG decode -> letterbox -> predict -> decode/NMS/top-k -> back-projection
     -> csv rows) on a synthetic UCCS-format folder: images/sec at the reference's batch 1 and with the read-ahead batches of
-    hps.eval_batch_size = 16 (face_detection.FaceDetector._detect_files).  Wall clock, host work included."""
+    hps.eval_batch_size = 16 / 32 (face_detection.FaceDetector._detect_files; 32 is the default).  Wall clock, host work included."""
     import numpy as np
     from PIL import Image
     from face_vijnana_yolov3_amd import face_detection
@@ -321,7 +321,7 @@ def test_loop_bench(device, S, n_img=64):
             fd.model.params[d['w_off']:d['beta_off']] *= 0.05
             fd.model.params[d['beta_off']] = 0.3; fd.model.params[d['beta_off'] + 5] = 0.3
             out = {}
-            for bs in (1, 16):
+            for bs in (1, 16, 32):
                 conf['hps']['eval_batch_size'] = bs
                 fd.test()                                 # warm-up (workspace, file cache)
                 t0 = time.perf_counter(); fd.test(); dt = time.perf_counter() - t0
@@ -329,8 +329,8 @@ def test_loop_bench(device, S, n_img=64):
             rows = sum(1 for _ in open(conf['output_file_path']))
         finally:
             face_detection.DEBUG = dbg
-    return dict(unit='images/sec', eval_batch_1=out['batch1'], eval_batch_16=out['batch16'], images=n_img, csv_rows=rows,
-                path='FaceDetector.test(): %d synthetic JPEGs (768x1024 .. 720x1280), Huffman decoding on 16 host threads one batch '
+    return dict(unit='images/sec', eval_batch_1=out['batch1'], eval_batch_16=out['batch16'], eval_batch_32=out['batch32'], images=n_img, csv_rows=rows,
+                path='FaceDetector.test(): %d synthetic JPEGs (768x1024 .. 720x1280), Huffman decoding on 16 host threads into reused pinned buffers one batch '
                      'ahead, fv_jpeg_reconstruct_batch, fv_letterbox_batch, fv_forward_infer, fv_decode_nms, back-projection, csv' % n_img)
 
 

@@ -13,7 +13,7 @@ ratios.csv, the model files).  Differences, all documented in DESIGN.md:
     starts num_gpus ranks itself (parallel.launch_ranks -> torch.distributed.run); a FaceDetector constructed directly in a
     process without WORLD_SIZE trains on one GPU
   * evaluate() tolerates images without ground-truth rows and a missing arial.ttf
-  * evaluate()/test() read ahead and run the network on batches of hps['eval_batch_size'] images (default 16; the
+  * evaluate()/test() read ahead and run the network on batches of hps['eval_batch_size'] images (default 32; the
     reference's loop is batch 1, fd.py:632-883) -- same rows in the same order
   * train() and test() decode baseline JPEGs in two halves (jpeg.py): Huffman decoding on host threads, dequantisation / IDCT /
     chroma upsampling / colour conversion on the device, bit-identical to Pillow's pixels (hps['device_jpeg'] = false: Pillow);
@@ -34,7 +34,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import data
-from .postproc import BoundBox, decode_nms, letterbox_batch_device, letterbox_device, pack_images, to_boundboxes
+from .postproc import BoundBox, PinnedRing, decode_nms, letterbox_batch_device, letterbox_device, pack_images, to_boundboxes
 
 DEBUG = True
 
@@ -181,16 +181,31 @@ class FaceDetector(object):
 
     def detect_batch(self, images):
         """(B,S,S,3) array or CUDA tensor -> one list[BoundBox] per image (what evaluate()/test() run per batch)."""
+        return self._detect_collect(self._detect_launch(images))
+
+    def _detect_launch(self, images):
+        """Queue network + decode/NMS/top-k for a batch and the copy of the (small) result into pinned host memory; no host sync.
+        evaluate()/test() queue batch k+1 before they read batch k (_detect_collect), so the device never waits for the host's
+        box bookkeeping."""
         import torch
         x = images if torch.is_tensor(images) else np.asarray(images, dtype=np.float32)
         if self.three_scale:
-            return self._detect_three_scale(x)
+            return ('three_scale', x)
         y = self.model.predict_device(x)
         res = decode_nms(self.model.ctx, y, self.image_size, self.hps['face_conf_th'], self.hps['nms_iou_th'],
                          self.hps['num_cands'])
-        # one D2H copy per tensor for the whole batch instead of four per image
-        host = {k: v.cpu() for k, v in res.items()}
-        return [to_boundboxes(host, b) for b in range(y.shape[0])]
+        # one D2H copy per tensor for the whole batch, ordered behind THIS batch's kernels only
+        host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True).copy_(v, non_blocking=True) for k, v in res.items()}
+        ev = torch.cuda.Event()
+        ev.record()
+        return ('single', host, ev, int(y.shape[0]))
+
+    def _detect_collect(self, launched):
+        if launched[0] == 'three_scale':
+            return self._detect_three_scale(launched[1])
+        _tag, host, ev, n = launched
+        ev.synchronize()
+        return [to_boundboxes(host, b) for b in range(n)]
 
     def _detect_three_scale(self, x):
         """Three-scale head: the reference's decode_netout -> correct_yolo_boxes -> do_nms chain (yolov3_detect.py:335-444,
@@ -242,13 +257,18 @@ class FaceDetector(object):
         """Yield (file_name, raw image, boxes in image coordinates) in file order.  The reference's evaluate()/test() loops
         (fd.py:632-883) decode, letterbox and predict one image at a time; here a thread pool decodes batch k+1 (PIL releases
         the GIL) while batch k is letterboxed in one launch (fv_letterbox_batch) and runs ONE forward + ONE decode/NMS launch
-        -- batch 1 is the slowest operating point of the network (1.3 ms/img against 0.4 at batch 16+)."""
-        bs = max(1, int(self.hps.get('eval_batch_size', 16)))
+        -- batch 1 is the slowest operating point of the network (1.3 ms/img against 0.4 at batch 16+).  Two deep: the loader
+        thread fills a reused pinned buffer (PinnedRing) with batch k+1 while batch k is in the device queue and the host turns
+        batch k-1's result into BoundBoxes and rows."""
+        bs = max(1, int(self.hps.get('eval_batch_size', 32)))
         chunks = [files[i:i + bs] for i in range(0, len(files), bs)]
         if not chunks:
             return
         threads = max(1, min(bs, int(self.hps.get('loader_threads', 8))))
         use_jpeg = not need_raw and bool(self.hps.get('device_jpeg', True))
+        if getattr(self, '_eval_ring', None) is None:
+            self._eval_ring = PinnedRing(3)          # kept across evaluate()/test() calls: page-locking is the expensive part
+        ring = self._eval_ring
         with ThreadPoolExecutor(max_workers=threads) as pool, ThreadPoolExecutor(max_workers=1) as one:
             def load(chunk):
                 if use_jpeg:       # test() never looks at the pixels on the host: Huffman-decode only, the rest on the device
@@ -258,23 +278,33 @@ class FaceDetector(object):
                     infos = [jpeg.parse(d) for d in datas]
                     if all(i is not None for i in infos):
                         plan = jpeg.BatchPlan(infos)
-                        buf = torch.empty(plan.total_coefs, dtype=torch.int16)
-                        if torch.cuda.is_available():
-                            buf = buf.pin_memory()
+                        buf = ring.take(2 * plan.total_coefs).view(torch.int16)     # decoded straight into a reused pinned buffer
                         view = buf.numpy()
                         list(pool.map(lambda i: jpeg.entropy_decode(datas[i], infos[i], view[plan.coef_off[i]:plan.coef_off[i] + int(infos[i].total_coefs)]),
                                       range(len(chunk))))
                         return None, ('jpeg', buf, plan)
-                return list(pool.map(data._pil_loader, chunk)), None
+                raws = list(pool.map(data._pil_loader, chunk))
+                return raws, pack_images(raws, ring=ring)
+            def finish(done):
+                chunk_, raws_, geoms_, launched = done
+                for i, (name, boxes, geom) in enumerate(zip(chunk_, self._detect_collect(launched), geoms_)):
+                    self._project_back(boxes, geom)
+                    yield name, (raws_[i] if raws_ is not None else None), boxes
+            prev = None
             pending = one.submit(load, chunks[0])
             for k, chunk in enumerate(chunks):
                 raws, packed = pending.result()
                 if k + 1 < len(chunks):
                     pending = one.submit(load, chunks[k + 1])
                 x, geoms = letterbox_batch_device(self.model.ctx, raws, self.image_size, self.model.dev, packed=packed)
-                for i, (name, boxes, geom) in enumerate(zip(chunk, self.detect_batch(x), geoms)):
-                    self._project_back(boxes, geom)
-                    yield name, (raws[i] if raws is not None else None), boxes
+                ring.copied(packed[1] if isinstance(packed[0], str) else packed[0])       # the H2D copy of the buffer is in the queue
+                cur = (chunk, raws, geoms, self._detect_launch(x))
+                if prev is not None:               # read batch k-1 now that batch k is in the queue
+                    for item in finish(prev):
+                        yield item
+                prev = cur
+            for item in finish(prev):
+                yield item
 
     def evaluate(self):
         import pandas as pd
@@ -353,11 +383,9 @@ class BatchFeeder(object):
         self.one = ThreadPoolExecutor(max_workers=1)
         self.device_jpeg = bool(seq.hps.get('device_jpeg', True))    # hps.device_jpeg = false: decode with Pillow on the host
         self.pending = None
-        # three pinned staging buffers, reused round-robin (allocating ~100 MB of pinned memory per batch costs more than
-        # decoding it); a buffer is rewritten only after the H2D copy that read it has completed (event recorded by the consumer)
-        self._pins = [None, None, None]
-        self._pin_events = [None, None, None]
-        self._pin_next = 0
+        # three pinned staging buffers, reused round-robin; a buffer is rewritten only after the H2D copy that read it has
+        # completed (event recorded by the consumer through copied())
+        self.ring = PinnedRing(3)
 
     def _load_jpeg(self, seq, names, pin):
         """The batch as quantised JPEG coefficients (jpeg.py): the files are read and Huffman-decoded by the pool straight into
@@ -372,7 +400,7 @@ class BatchFeeder(object):
         plan = jpeg.BatchPlan(infos)
         slot = None
         if pin:
-            slot, raw = self._pinned(2 * plan.total_coefs)
+            raw = slot = self.ring.take(2 * plan.total_coefs)
             buf = raw.view(torch.int16)
         else:
             buf = torch.empty(plan.total_coefs, dtype=torch.int16)
@@ -381,23 +409,9 @@ class BatchFeeder(object):
                            range(len(names))))
         return ('jpeg', buf, plan), [(i.height, i.width) for i in infos], slot
 
-    def _pinned(self, nbytes):
-        import torch
-        i = self._pin_next
-        self._pin_next = (i + 1) % 3
-        if self._pin_events[i] is not None:
-            self._pin_events[i].synchronize()
-            self._pin_events[i] = None
-        if self._pins[i] is None or self._pins[i].numel() < nbytes:
-            self._pins[i] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
-        return i, self._pins[i][:nbytes]
-
     def copied(self, slot):
-        """Called by the consumer right after it enqueued the H2D copy of the buffer in `slot`."""
-        import torch
-        ev = torch.cuda.Event()
-        ev.record()
-        self._pin_events[slot] = ev
+        """Called by the consumer right after it enqueued the H2D copy of the buffer `slot` (on the stream that copies)."""
+        self.ring.copied(slot)
 
     def load(self, index):
         import torch
@@ -424,7 +438,7 @@ class BatchFeeder(object):
                 hw += [h, w]; offs.append(o); o += h * w * 3
             slot = None
             if pin:
-                slot, buf = self._pinned(o)
+                buf = slot = self.ring.take(o)
             else:
                 buf = torch.empty(o, dtype=torch.uint8)
             view = buf.numpy()

@@ -86,14 +86,53 @@ def letterbox_device(ctx, raw_u8, image_size, out=None):
     return out, (h, w, geom[2], geom[3], geom[4], geom[5])
 
 
-def pack_images(raws, pin=True):
+class PinnedRing(object):
+    """A few pinned host buffers reused round-robin.  Page-locking a fresh 35-100 MB buffer costs 50-160 ms on this stack whenever
+    torch's pinned-memory cache holds no block of that size (tools/eval_load_probe.py: batches differ in size, so every second or
+    third batch missed) -- more than decoding the batch -- so the loaders write into these instead.  take() hands out the next
+    buffer (grown with 25 % slack when too small) once the H2D copy that last read it has completed; the consumer calls
+    copied(buffer) right after it enqueued that copy."""
+
+    def __init__(self, n=3):
+        self._pins = [None] * n
+        self._events = [None] * n
+        self._next = 0
+
+    def take(self, nbytes):
+        """-> uint8 pinned tensor of nbytes (a view of the slot's buffer)."""
+        import torch
+        i = self._next
+        self._next = (i + 1) % len(self._pins)
+        if self._events[i] is not None:
+            self._events[i].synchronize()
+            self._events[i] = None
+        if self._pins[i] is None or self._pins[i].numel() < nbytes:
+            self._pins[i] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+        return self._pins[i][:nbytes]
+
+    def copied(self, buf):
+        """An event on the current stream guards the slot `buf` (any view of it) came from."""
+        import torch
+        p = buf.data_ptr()
+        for i, b in enumerate(self._pins):
+            if b is not None and b.data_ptr() <= p < b.data_ptr() + max(b.numel(), 1):
+                ev = torch.cuda.Event()
+                ev.record()
+                self._events[i] = ev
+                return
+
+
+def pack_images(raws, pin=True, ring=None):
     """Host side of fv_letterbox_batch: the decoded uint8 images back to back in ONE (pinned) host
-    buffer -> (uint8 tensor, offsets int64 list, hw list)."""
+    buffer -> (uint8 tensor, offsets int64 list, hw list).  ring: a PinnedRing to take the buffer from."""
     import torch
     sizes = [int(r.shape[0]) * int(r.shape[1]) * 3 for r in raws]
-    buf = torch.empty(sum(sizes), dtype=torch.uint8)
-    if pin and torch.cuda.is_available():
-        buf = buf.pin_memory()
+    if ring is not None and pin and torch.cuda.is_available():
+        buf = ring.take(sum(sizes))
+    else:
+        buf = torch.empty(sum(sizes), dtype=torch.uint8)
+        if pin and torch.cuda.is_available():
+            buf = buf.pin_memory()
     view = buf.numpy()
     offs, hw, o = [], [], 0
     for r, n in zip(raws, sizes):
