@@ -337,7 +337,7 @@ def test_loop_bench(device, S, n_img=128):
 def three_scale_bench(device, S, B=16, steps=3):
     """one training step of the full three-scale YOLOv3 graph (75 convs, two upsample+concat routes,
     255 output channels, the build's objectness/box/class loss, Adam) -- device-resident synthetic batch.  A secondary
-    number beside `value`; this path has no side-stream overlap yet."""
+    number beside `value`; weight-gradients overlap the data-gradient chain on the side stream as in fv_train_step."""
     import torch
     from face_vijnana_yolov3_amd.yolov3 import Yolov3
     m = Yolov3(device, out_channels=255)

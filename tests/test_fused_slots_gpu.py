@@ -353,3 +353,48 @@ def test_halo_stride2_dgrad_is_bit_identical_to_the_tile_kernel(ctx, B, H, ndy, 
         mag = torch.stack([gy.abs().sum(0), (gy * xhat).abs().sum(0)]).cpu()
         assert ((s1 - ref).abs() <= 2e-6 * mag + 1e-9).all(), (s1 - ref).abs().max().item()
         assert ((s1 - s0).abs() <= 2e-5 * mag + 1e-6).all()
+
+
+@pytest.mark.parametrize('B', [14500, 14600])
+def test_halo_forward_next_to_the_2_gib_output_bound(ctx, B):
+    """conv9_mfma.hip masks edge stores with the 32-bit byte offset 0x80000000, which must lie beyond the output: the halo kernel
+    takes outputs below 2 GiB (B = 14500 at 24x24x64: 2.138e9 bytes, partial 8x16 units at the bottom and right edges) and leaves
+    larger ones (B = 14600: 2.153e9) to the tile kernel.  Either way the first and last images must be bit-identical to the same
+    images convolved on their own (before the guard, masked stores of the larger case landed inside the tensor)."""
+    from face_vijnana_yolov3_amd import ops
+    H = 24
+    g = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.rand((B, H, H, 32), generator=g, device='cuda') * 2 - 1
+    w = _rand((64, 3, 3, 32), 92, -0.2, 0.2).cuda()
+    assert (B * H * H * 64 * 4 >= 2 ** 31) == (B == 14600)
+    z = ops.conv2d_forward_slots(ctx, x, w, 1, ops.stat_slots(64, 'cuda'))
+    for sl in (slice(0, 3), slice(B // 2, B // 2 + 3), slice(B - 3, B)):
+        part = ops.conv2d_forward_slots(ctx, x[sl].contiguous(), w, 1, ops.stat_slots(64, 'cuda'))
+        assert torch.equal(z[sl], part)
+    ctx.set_conv_halo(False)
+    try:
+        part0 = ops.conv2d_forward_slots(ctx, x[B - 3:].contiguous(), w, 1, ops.stat_slots(64, 'cuda'))
+    finally:
+        ctx.set_conv_halo(True)
+    assert torch.equal(z[B - 3:], part0)
+
+
+@pytest.mark.parametrize('B', [8600, 8700])
+def test_halo_stride2_dgrad_next_to_the_2_gib_output_bound(ctx, B):
+    """Same bound for dgrad9s2_mfma.hip (dx of the 32 -> 64 stride-2 layer, 44x44x32 per image: 2.131e9 bytes at B = 8600,
+    2.156e9 at B = 8700; 44 is not a multiple of the unit, so edge units are partial)."""
+    from face_vijnana_yolov3_amd import ops
+    H = 44
+    g = torch.Generator(device='cuda').manual_seed(8)
+    dy = torch.rand((B, H // 2, H // 2, 64), generator=g, device='cuda') * 2 - 1
+    w = _rand((64, 3, 3, 32), 101, -0.2, 0.2).cuda()
+    assert (B * H * H * 32 * 4 >= 2 ** 31) == (B == 8700)
+    dx = ops.conv2d_dgrad(ctx, dy, w, (H, H), 2)
+    for sl in (slice(0, 3), slice(B - 3, B)):
+        assert torch.equal(dx[sl], ops.conv2d_dgrad(ctx, dy[sl].contiguous(), w, (H, H), 2))
+    ctx.set_conv_halo(False)
+    try:
+        part0 = ops.conv2d_dgrad(ctx, dy[B - 3:].contiguous(), w, (H, H), 2)
+    finally:
+        ctx.set_conv_halo(True)
+    assert torch.equal(dx[B - 3:], part0)
