@@ -631,6 +631,7 @@ void fv_conv_tail_plan(int M, int Nout, int ksteps, int* tail_f, int* tail_full,
     // (~17 us with its gap) and moves (f + 1) tiles of 64 KiB per tail tile.
     auto round_us = [](int nwg, int steps) { return (nwg <= 256 ? 2.25 : 3.8) * steps + 8.0; };
     const double unsplit = round_us(R, ksteps);
+    // (A) every tile of the last round cut into f slices
     double best = unsplit;
     int best_f = 1;
     for (int f = 2; f <= 8 && ksteps / f >= 4; ++f) {
@@ -640,7 +641,29 @@ void fv_conv_tail_plan(int M, int Nout, int ksteps, int* tail_f, int* tail_full,
         c += 17.0 + 15.0 + (double)R * (f + 1) * 65536.0 / 4.5e6;
         if (c < best) { best = c; best_f = f; }
     }
-    if (best_f > 1 && unsplit - best >= 10.0 && best <= 0.95 * unsplit) {
+    const bool a_ok = best_f > 1 && unsplit - best >= 10.0 && best <= 0.95 * unsplit;
+    // (B) a last round of 257 ... 511 tiles leaves some CUs with one workgroup, which then runs 1.7x as fast and idles for
+    // the rest of the round.  Keep 256 of those tiles whole -- one per CU -- and cut the others into f slices that fill the
+    // second slot of every CU in turn: a CU's whole tile shares the pipe with n = ceil(slices / 256) slices one after the
+    // other and has it to itself afterwards.  Measured (tools/layer_bench.py, batch 40): the 424-tile launches (13x13 forward,
+    // 26x26 data-gradient, 144 K steps) 0.531 -> 0.450 ms = 120 -> 142 TF, the 845- / 848-tile ones 0.476 -> 0.451 and
+    // 0.463 -> 0.450 ms; the model below is conservative (it predicts 0.538 for the first), so (B) is taken whenever it predicts
+    // any gain, also where (A) qualifies: 53.25 -> 52.5 ms per training step.
+    double bestb = unsplit; int fb = 1;
+    if (R > 256) {
+        const int Rb = R - 256;
+        for (int f = 2; f <= 8 && ksteps / f >= 4; ++f) {
+            const int per = (ksteps + f - 1) / f, P = Rb * f, n = (P + 255) / 256;
+            if ((f - 1) * per >= ksteps || n * per > ksteps) continue;
+            double c = n * (per * 3.8 + 8.0) + (ksteps - n * per) * 2.25 + 8.0;
+            c += 17.0 + 15.0 + (double)Rb * (f + 1) * 65536.0 / 4.5e6;
+            if (c < bestb) { bestb = c; fb = f; }
+        }
+    }
+    const bool b_ok = fb > 1 && unsplit - bestb >= 5.0;
+    if (b_ok) {
+        *tail_f = fb; *tail_full = full + 256; *slab_floats = (long long)(R - 256) * fb * BM * 128;
+    } else if (a_ok) {
         *tail_f = best_f; *tail_full = full; *slab_floats = (long long)R * best_f * BM * 128;
     }
 }

@@ -194,12 +194,14 @@ def test_conv_wgrad(ctx, B, H, cin, cout, k, s, ndy):
     _check(got, ref, bound, 'wgrad')
 
 
-def test_conv_tail_split_with_lent_scratch(ctx):
-    """fv_set_conv_scratch: 307 output tiles of 72 K steps -> the launcher cuts every tile into 3 K slices
-    and the fix-up kernel applies the epilogue.  Forward (raw + BN partial sums, fused affine/leaky/add)
-    and stride-1 data-gradient against float64; the unsplit launch differs only in rounding."""
+@pytest.mark.parametrize('H', [140, 100])
+def test_conv_tail_split_with_lent_scratch(ctx, H):
+    """fv_set_conv_scratch, both plans of fv_conv_tail_plan: H = 100 -> 157 output tiles of 72 K steps, every tile cut into K
+    slices; H = 140 -> 307 tiles, 256 stay whole (one per CU) and the other 51 are cut into slices that fill the second slot of
+    the CUs.  The fix-up kernel applies the epilogue.  Forward (raw + BN partial sums, fused affine/leaky/add) and stride-1
+    data-gradient against float64; the unsplit launch differs only in rounding."""
     from face_vijnana_yolov3_amd import ops
-    B, H, cin, cout = 2, 140, 256, 128
+    B, cin, cout = 2, 256, 128
     x = _rand((B, H, H, cin), 31); w = _rand((cout, 3, 3, cin), 32, -0.1, 0.1)
     scale = _rand((cout,), 33, 0.5, 1.5); shift = _rand((cout,), 34); skip = _rand((B, H, H, cout), 35)
     ref = _ref_conv(x.double(), w.double(), 3, 1)
