@@ -12,12 +12,12 @@ out=$root/gpurun_out
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 python3 -c "import sys; sys.path.insert(0, '$root'); from face_vijnana_yolov3_amd.build import source_fingerprint; print(source_fingerprint())" > "$out/${tag}_fingerprint.txt"
-common="--steps 5 --warmup 2 --no-cpu-baseline --no-detect --no-loader"
+common="--steps 5 --warmup 2 --no-cpu-baseline --no-detect --no-loader --no-rccl-rehearsal"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_serial" -o run -- python3 "$root/bench.py" $common --no-overlap > "$out/${tag}_serial_bench.json" 2> "$out/${tag}_serial.err"
 echo "serial done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_overlap" -o run -- python3 "$root/bench.py" $common > "$out/${tag}_overlap_bench.json" 2> "$out/${tag}_overlap.err"
 echo "overlap done"
-pmc="--steps 1 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-overlap --no-detect --no-loader"
+pmc="--steps 1 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-overlap --no-detect --no-loader --no-rccl-rehearsal"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmc_fetch" -o run -- python3 "$root/bench.py" $pmc > "$out/${tag}_pmc_fetch_bench.json" 2> "$out/${tag}_pmc_fetch.err"
 echo "fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmc_write" -o run -- python3 "$root/bench.py" $pmc > "$out/${tag}_pmc_write_bench.json" 2> "$out/${tag}_pmc_write.err"
