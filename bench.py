@@ -390,10 +390,10 @@ def rccl_world1_rehearsal(eng, x, y, steps=10):
             return (time.perf_counter() - t0) / steps * 1e3
         plain_ms = timed(lambda: eng.train_on_batch(x, y, **HPS))           # the same loop without the DP machinery, for comparison
         dist.init_process_group('nccl', store=dist.HashStore(), rank=0, world_size=1, device_id=eng.dev)
-        tr = DataParallelTrainer(eng, world_size=1, rank=0, force_bucket_path=True, comm_mode='pg')
+        tr = DataParallelTrainer(eng, world_size=1, rank=0, force_bucket_path=True, comm_mode='wg')
         ms = timed(lambda: tr.train_on_batch(x, y, **HPS))
         tr_auto = DataParallelTrainer(eng, world_size=1, rank=0, force_bucket_path=True, comm_mode='auto')
-        for _ in range(32):                     # the default mode: measures 'pg' and 'main' over its first steps, keeps the faster
+        for _ in range(32):                     # the default mode: measures 'wg' and 'main' over its first steps, keeps the faster
             if not tr_auto.calibrating:
                 break
             tr_auto.train_on_batch(x, y, **HPS)
@@ -408,7 +408,7 @@ def rccl_world1_rehearsal(eng, x, y, steps=10):
                    gradient_mb=round(eng.n_params * 4 / 1e6, 2), collectives_per_step=n_coll, allreduce_ms=round(ar, 3), comm_mode=tr.comm_mode,
                    auto=tr_auto.auto_report, ms_per_step=round(ms, 3), blocking_on_compute_stream_ms_per_step=round(main_ms, 3),
                    plain_ms_per_step_same_loop=round(plain_ms, 3), steps=steps,
-                   note='world-size-1 nccl group on this GPU: bucketed all_reduce calls (async, on the group\'s own stream) overlapped with backward')
+                   note='world-size-1 nccl group on this GPU: bucketed all_reduce calls on the weight-gradient stream, beside the data-gradient chain')
         dist.destroy_process_group()
         return out
     except Exception as e:      # the headline number must not depend on this rehearsal
@@ -562,7 +562,7 @@ def main():
         compute_ms = (time.perf_counter() - t1) / k * 1e3
         # the same data-parallel step with the collectives BLOCKING on the compute stream (no overlap, no cross-stream traffic):
         # on one GPU that form is 2.5 ms per step cheaper than any overlapped one (parallel.DataParallelTrainer); which wins here?
-        alt = DataParallelTrainer(eng, world_size=world, rank=rank, comm_mode='main' if trainer.comm_mode != 'main' else 'pg')
+        alt = DataParallelTrainer(eng, world_size=world, rank=rank, comm_mode='main' if trainer.comm_mode != 'main' else 'wg')
         for _ in range(3):
             alt.train_on_batch(x, y, **HPS)
         torch.cuda.synchronize(); trainer.barrier()

@@ -63,6 +63,8 @@ def _declare(L):
     sig = {
         'fv_set_overlap': (i32, [vp, i32]),
         'fv_set_tail_split': (i32, [vp, i32]),
+        'fv_set_bucket_on_side': (i32, [vp, i32]),
+        'fv_side_stream': (vp, [vp]),
         'fv_set_conv_scratch': (i32, [vp, vp, sz]),
         'fv_set_conv0_direct': (i32, [vp, i32]),
         'fv_set_conv_waves8': (i32, [vp, i32]),
@@ -130,6 +132,7 @@ class Context:
         torch.cuda.set_device(self.device)
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.overlap = True            # fv_set_overlap's state (the library's default)
         self._h = c_void_p()
         rc = lib().fv_create(self.device, c_void_p(stream), ctypes.byref(self._h))
         if rc != 0:
@@ -148,6 +151,14 @@ class Context:
 
     def set_overlap(self, on):
         self.check(lib().fv_set_overlap(self._h, 1 if on else 0), 'fv_set_overlap')
+        self.overlap = bool(on)
+
+    def set_bucket_on_side(self, on):
+        self.check(lib().fv_set_bucket_on_side(self._h, 1 if on else 0), 'fv_set_bucket_on_side')
+
+    def side_stream(self):
+        """hipStream_t of the library's side stream (int), for torch.cuda.ExternalStream."""
+        return int(lib().fv_side_stream(self._h) or 0)
 
     def set_tail_split(self, on):
         self.check(lib().fv_set_tail_split(self._h, 1 if on else 0), 'fv_set_tail_split')

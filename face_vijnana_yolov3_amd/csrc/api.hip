@@ -54,6 +54,14 @@ int fv_set_overlap(fv_ctx* ctx, int on) {
     return FV_OK;
 }
 
+int fv_set_bucket_on_side(fv_ctx* ctx, int on) {
+    if (!ctx) return FV_ERR_INVALID;
+    ctx->bucket_on_side = on != 0;
+    return FV_OK;
+}
+
+void* fv_side_stream(fv_ctx* ctx) { return ctx ? (void*)ctx->side : nullptr; }
+
 int fv_set_tail_split(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;
     ctx->tail_split = on != 0;

@@ -24,6 +24,7 @@ struct fv_ctx {
     // data-gradient / BN-backward chain (fv_set_overlap)
     bool overlap = true;
     hipStream_t side = nullptr;
+    bool bucket_on_side = false;   // fv_set_bucket_on_side: fv_bucket_fn fires when the range's weight-gradient is in the side stream's queue
     hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr};
     // scratch for the conv tail split (conv.h); lent by the network-level entry points out of the
     // caller's workspace for the duration of one call, NULL otherwise

@@ -366,11 +366,12 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
     // waited for
     const bool ov = ctx->overlap && ctx->side;
     hipStream_t main_stream = ctx->stream;
+    const bool early = ov && ctx->bucket_on_side;      // the callback fires at enqueue time and works on the side stream
     struct Pending { bool on; int64_t off, cnt; } pend[2] = {{false, 0, 0}, {false, 0, 0}};
     auto join = [&](int par) -> int {
         if (!pend[par].on) return FV_OK;
         FV_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_wg[par], 0));
-        if (on_bucket) on_bucket(user, pend[par].off, pend[par].cnt);
+        if (on_bucket && !early) on_bucket(user, pend[par].off, pend[par].cnt);
         pend[par].on = false;
         return FV_OK;
     };
@@ -401,6 +402,7 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
             int rc = fv_op_conv_wgrad(ctx, xin, dz, batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off);
             ctx->stream = main_stream;
             if (rc) return rc;
+            if (early && on_bucket) on_bucket(user, d.w_off, cnt);      // may enqueue a collective on the side stream
             FV_HIP(ctx, hipEventRecord(ctx->ev_wg[par], ctx->side));
             pend[par] = Pending{true, d.w_off, cnt};
         } else {

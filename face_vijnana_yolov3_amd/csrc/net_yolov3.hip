@@ -440,12 +440,14 @@ int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, cons
     // A layer's gradient range [w_off, + kernel + (gamma, beta | bias)) is complete once its weight-gradient has finished: it is
     // handed to the bucket callback when ev_wg[slot] has been waited for (the slots alternate strictly, so ranges are reported
     // in issue order = reverse execution order = descending offsets, the protocol of fv_train_step).
+    // fv_set_bucket_on_side: the callback fires when the weight-gradient is in the side stream's queue and works on that stream.
+    const bool early = ov && ctx->bucket_on_side;
     struct Pending { bool on; int64_t off, cnt; } pend[2] = {{false, 0, 0}, {false, 0, 0}};
     int slot = 0;
     auto join = [&](int s) -> int {
         if (!pend[s].on) return FV_OK;
         FV_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_wg[s], 0));
-        if (on_bucket) on_bucket(user, pend[s].off, pend[s].cnt);
+        if (on_bucket && !early) on_bucket(user, pend[s].off, pend[s].cnt);
         pend[s].on = false;
         return FV_OK;
     };
@@ -463,6 +465,7 @@ int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, cons
         const int rc = fv_op_conv_wgrad(ctx, xin, dyv, B, H, H, d.cin, d.cout, ndy, d.ksize, d.stride, dw);
         ctx->stream = main_stream;
         if (rc) return rc;
+        if (early && on_bucket) on_bucket(user, d.w_off, cnt);      // may enqueue a collective on the side stream
         FV_HIP(ctx, hipEventRecord(ctx->ev_wg[s], ctx->side));
         pend[s] = Pending{true, d.w_off, cnt};
         return FV_OK;

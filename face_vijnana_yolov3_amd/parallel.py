@@ -68,7 +68,12 @@ class DataParallelTrainer(object):
         self.reducer = None
         self.bucketed = self.world > 1 or force_bucket_path  # force: exercise the stream/bucket path on 1 GPU
         # Where the collectives run (FV_COMM_STREAM):
-        #   'pg'   (default) dist.all_reduce(async_op=True): the collective runs on the process group's OWN stream, ordered after the
+        #   'wg'   on the library's weight-gradient (side) stream, where the gradients are made: fv_bucket_fn fires as soon as a
+        #          range's weight-gradient kernels are in that stream's queue (fv_set_bucket_on_side) and a BLOCKING all_reduce is
+        #          enqueued there -- it blocks the side stream only, the data-gradient chain on the compute stream runs on beside
+        #          it and no event passes between the compute stream and the communication until the join at the end of the
+        #          backward pass.  Costs nothing at one rank (52.2 ms per step, as 'main'; tools/dp_trace.py);
+        #   'pg'   dist.all_reduce(async_op=True): the collective runs on the process group's OWN stream, ordered after the
         #          compute stream's work so far by the backend, and the compute stream waits for all of them before Adam -- the
         #          overlap with the rest of the backward pass without a second hop;
         #   'side' a communication stream of this trainer (compute -> event -> comm stream -> blocking all_reduce -> backend stream
@@ -80,15 +85,17 @@ class DataParallelTrainer(object):
         # independent of the number of buckets (7, 4 or 2 collectives per step: 56.0-56.6).  Whether hiding the real all-reduce
         # (about 1 ms for 162 MB over seven xGMI links, if RCCL reaches its usual bus bandwidth) is worth that on 8 GPUs is for
         # the first multi-GPU run to say: bench.py times both 'pg' and 'main' there (multi_gpu.alt_main_ms_per_step).
-        #   'auto' (default) the first AUTO_WARM + 2 * AUTO_STEPS + 1 optimisation steps time 'pg' and then 'main' (max over ranks,
+        #   'auto' (default) the first AUTO_WARM + 2 * AUTO_STEPS + 1 optimisation steps time 'wg' and then 'main' (max over ranks,
         #          so every rank decides alike) and the faster one is kept -- self.auto_report says what was measured.
+        # 'pg' / 'side' put 60 us bubbles in front of two dozen kernels of the backward pass and stretch the rest (rocprofv3
+        # timeline of tools/dp_trace.py: 55.6 against 52.2 ms per step at one rank); kept selectable for comparison.
         self.comm_mode = comm_mode or os.environ.get('FV_COMM_STREAM', 'auto')
-        if self.comm_mode not in ('pg', 'side', 'main', 'auto'):
-            raise ValueError("FV_COMM_STREAM must be 'auto', 'pg', 'side' or 'main'")
+        if self.comm_mode not in ('pg', 'side', 'main', 'auto', 'wg'):
+            raise ValueError("FV_COMM_STREAM must be 'auto', 'wg', 'pg', 'side' or 'main'")
         self.auto_report = None
         self._auto_k = None
         if self.comm_mode == 'auto':
-            self.comm_mode = 'pg'
+            self.comm_mode = 'wg'
             # resolved in train_on_batch (needs a process group to be worth measuring); a trainer without the bucket path has
             # no collectives and nothing to decide
             self._auto_k = 0 if self.bucketed else None
@@ -97,6 +104,7 @@ class DataParallelTrainer(object):
         if self.bucketed:
             if self.comm_mode == 'side':
                 self.comm = torch.cuda.Stream(device=engine.dev, priority=int(os.environ.get('FV_COMM_PRIORITY', '0')))
+            self.wg_stream = torch.cuda.ExternalStream(engine.ctx.side_stream(), device=engine.dev)
             engine.ensure_optimizer()
             self.reducer = BucketReducer(engine.grads, self.world, bucket_bytes, self._launch)
         self._own_group = False
@@ -122,6 +130,14 @@ class DataParallelTrainer(object):
 
     def _launch(self, view):
         """One bucket: scale by n_rank / n_total (SUM over ranks = gradient of the merged-batch mean), all-reduce."""
+        if self.comm_mode == 'wg' and self.eng.ctx.overlap:      # without the overlap the library reports ranges on its own stream
+            with torch.cuda.stream(self.wg_stream):
+                if self._weight != 1.0:
+                    view.mul_(self._weight)
+                if self.collective:
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM)      # blocking for the SIDE stream only
+                    self.collectives_launched += 1
+            return
         if self.comm_mode == 'side':
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.eng.dev))
@@ -146,7 +162,7 @@ class DataParallelTrainer(object):
     AUTO_WARM, AUTO_STEPS = 3, 4
 
     def _auto_tick(self):
-        """comm_mode 'auto': called at the top of every step until decided.  Steps [0, W) warm up in 'pg', [W, W+S) time 'pg',
+        """comm_mode 'auto': called at the top of every step until decided.  Steps [0, W) warm up in 'wg', [W, W+S) time 'wg',
         step W+S warms 'main', [W+S+1, W+2S+1) time 'main'; at step W+2S+1 the two times are max-reduced over the ranks and the
         faster mode is kept.  Three host synchronisations in all; every step of the calibration is an ordinary training step."""
         import time
@@ -163,9 +179,9 @@ class DataParallelTrainer(object):
             elif k == W + 2 * S + 1:
                 t = torch.tensor([self._auto_pg, (now - self._auto_t0) / S * 1e3], dtype=torch.float64, device=self.eng.dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                pg_ms, main_ms = (float(v) for v in t.cpu())
-                self.comm_mode = 'pg' if pg_ms < main_ms else 'main'
-                self.auto_report = dict(pg_ms_per_step=round(pg_ms, 3), main_ms_per_step=round(main_ms, 3), chosen=self.comm_mode,
+                wg_ms, main_ms = (float(v) for v in t.cpu())
+                self.comm_mode = 'wg' if wg_ms < main_ms else 'main'
+                self.auto_report = dict(wg_ms_per_step=round(wg_ms, 3), main_ms_per_step=round(main_ms, 3), chosen=self.comm_mode,
                                         steps_each=S)
                 self._auto_k = None
                 return
@@ -201,9 +217,12 @@ class DataParallelTrainer(object):
         if self._auto_k is not None:
             self._auto_tick()
         self._weight = float(weight) if weight is not None else 1.0 / self.world
+        eng.ctx.set_bucket_on_side(self.comm_mode == 'wg')       # per step: several trainers may share one context
         self.reducer.reset()
         loss = eng.forward_backward(x, y, on_bucket=self.reducer.on_range)
         self.reducer.flush()
+        if self.comm_mode == 'wg' and eng.ctx.overlap:       # the last bucket went out after fv_train_step had joined the side stream
+            torch.cuda.current_stream(eng.dev).wait_stream(self.wg_stream)
         # BN moving statistics: the reference's towers race on shared variables (undefined order); we keep ranks identical
         # by averaging (parity unpinned)
         if self.comm_mode == 'side':

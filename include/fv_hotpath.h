@@ -48,6 +48,13 @@ int fv_set_stream(fv_ctx* ctx, void* stream);
  * of a gradient range (fv_bucket_fn) and before it returns.  on = 0 serialises everything on the
  * context's stream (default: on). */
 int fv_set_overlap(fv_ctx* ctx, int on);
+/* Where fv_bucket_fn fires.  Default (0): after the context's stream has been made to wait for the range's weight-gradient --
+ * work the callback enqueues on the context's stream sees the finished range.  on = 1 (with the overlap on): as soon as the
+ * range's weight-gradient kernels are in the SIDE stream's queue -- the callback must enqueue its work (the all-reduce of the
+ * bucket) on fv_side_stream(ctx), where it is ordered behind them and runs beside the data-gradient chain without an event
+ * between the context's stream and the communication; the side stream is joined before fv_train_step returns. */
+int fv_set_bucket_on_side(fv_ctx* ctx, int on);
+void* fv_side_stream(fv_ctx* ctx);   /* the hipStream_t of the internal side stream */
 /* Tail split of the conv launches inside fv_train_step / fv_forward_infer: when the 128x128 output
  * tiles of a layer do not fill a whole number of rounds of the 512 resident workgroup slots, the
  * tiles of the last partial round are cut into K slices (one workgroup each) whose partial tiles a

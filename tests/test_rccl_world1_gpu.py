@@ -46,16 +46,29 @@ for mode in ('plain', 'rccl'):
         assert all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
         assert ncoll == 3 * (len(cover) + 1), (ncoll, len(cover))    # every bucket of every step + the BN state went through all_reduce
         assert tr.max_over_ranks(1.5) == 1.5
-        # the default comm mode is 'auto': overlapped ('pg') while it calibrates, then 'pg' and 'main' timed and one kept
-        assert tr.calibrating and tr.comm_mode == 'pg'
+        # the default comm mode is 'auto': overlapped ('wg': on the weight-gradient stream) while it calibrates, then 'wg' and
+        # 'main' timed and one kept
+        assert tr.calibrating and tr.comm_mode == 'wg'
         n = 3
         while tr.calibrating:
             tr.train_on_batch(x, y, 1e-4, 0.99, 0.99); n += 1
         rep = tr.auto_report
-        assert n == tr.AUTO_WARM + 2 * tr.AUTO_STEPS + 2 and rep['chosen'] == tr.comm_mode and rep['chosen'] in ('pg', 'main'), (n, rep)
-        assert rep['pg_ms_per_step'] > 0 and rep['main_ms_per_step'] > 0
+        assert n == tr.AUTO_WARM + 2 * tr.AUTO_STEPS + 2 and rep['chosen'] == tr.comm_mode and rep['chosen'] in ('wg', 'main'), (n, rep)
+        assert rep['wg_ms_per_step'] > 0 and rep['main_ms_per_step'] > 0
         assert tr.collectives_launched == n * (len(cover) + 1)
         assert torch.isfinite(eng.params).all()
+        # Stream ordering of every comm mode, on hardware: with weight 0.5 the bucket is SCALED (a kernel of its own) at the very
+        # point of the stream where the collective is enqueued -- on the weight-gradient stream for 'wg', the compute stream for
+        # 'main' / 'pg', the trainer's stream for 'side'.  A scaling that ran before the range's weight-gradient kernels had
+        # finished would leave part of the gradient unscaled.
+        for cm in ('wg', 'main', 'pg', 'side'):
+            eng.init_synthetic(seed=7)
+            eng.iterations = 0; eng.m = eng.v = eng.grads = None
+            t2 = DataParallelTrainer(eng, world_size=1, rank=0, bucket_bytes=8 << 20, force_bucket_path=True, comm_mode=cm)
+            t2.train_on_batch(x, y, 1e-4, 0.99, 0.99, weight=0.5)
+            torch.cuda.synchronize()
+            rel = ((eng.grads - 0.5 * res[0][1]).norm() / (0.5 * res[0][1]).norm()).item()
+            assert rel <= 1e-5, (cm, rel)
         tr.barrier()
         dist.destroy_process_group()
 # first step: same loss, same (all-reduced) gradient and first Adam moment up to the float-atomic order inside dW
@@ -91,4 +104,4 @@ def test_bench_through_its_own_launcher_on_one_gpu():
     assert d['n_gpus'] == 1 and d['value'] > 0 and d['median_ms_per_step'] > 0
     assert d['multi_gpu'] and d['multi_gpu'].get('rccl_ranks') == 1 and d['multi_gpu']['backend'] == 'nccl', d['multi_gpu']
     assert d['multi_gpu']['collectives_per_step'] >= 5
-    assert d['multi_gpu']['auto']['chosen'] in ('pg', 'main')
+    assert d['multi_gpu']['auto']['chosen'] in ('wg', 'main')
