@@ -80,11 +80,8 @@ class DataParallelTrainer(object):
         #          and back): the round-1/2 form; FV_COMM_PRIORITY sets its priority (-1 = high);
         #   'main' blocking all_reduce on the compute stream (no overlap).
         # Measured on one MI355X with a world-size-1 nccl group (no RCCL kernel runs there: the stream / event traffic alone;
-        # tools/dp_overhead2.py, plain step 53.9 ms on that box): 'pg' 56.8, 'side' 56.8 (66.3 at high priority, 61.7 with
-        # GPU_MAX_HW_QUEUES=8), 'main' 54.3 -- a fixed 2.7-2.9 ms per step for ANY collective that is not waited for at once,
-        # independent of the number of buckets (7, 4 or 2 collectives per step: 56.0-56.6).  Whether hiding the real all-reduce
-        # (about 1 ms for 162 MB over seven xGMI links, if RCCL reaches its usual bus bandwidth) is worth that on 8 GPUs is for
-        # the first multi-GPU run to say: bench.py times both 'pg' and 'main' there (multi_gpu.alt_main_ms_per_step).
+        # tools/dp_overhead2.py, tools/dp_trace.py; plain step 52.2 ms): 'wg' 52.2, 'main' 52.2, 'pg' 55.6, 'side' the same as
+        # 'pg' (worse at high priority or with GPU_MAX_HW_QUEUES=8), independent of the number of buckets.
         #   'auto' (default) the first AUTO_WARM + 2 * AUTO_STEPS + 1 optimisation steps time 'wg' and then 'main' (max over ranks,
         #          so every rank decides alike) and the faster one is kept -- self.auto_report says what was measured.
         # 'pg' / 'side' put 60 us bubbles in front of two dozen kernels of the backward pass and stretch the rest (rocprofv3
