@@ -49,13 +49,20 @@ def _fn():
     return L
 
 
+# Pillow refuses images of more than 2 x Image.MAX_IMAGE_PIXELS pixels; a header claiming more is damaged or hostile, and the
+# coefficient buffer for it would be page-locked before anything could notice
+MAX_PIXELS = 178956970
+
+
 def parse(data):
     """JPEG bytes -> JpegInfo, or None when the file is not one this decoder takes (progressive, arithmetic-coded, CMYK, 12-bit,
     unusual sampling, damaged header)."""
     info = JpegInfo()
     data = data if isinstance(data, bytes) else bytes(data)
     rc = _fn().fv_jpeg_parse(ctypes.c_char_p(data), len(data), ctypes.byref(info))
-    return info if rc == 0 else None
+    if rc != 0 or info.width * info.height > MAX_PIXELS:
+        return None          # implausible size (damaged header): left to Pillow, whose decompression-bomb check raises
+    return info
 
 
 def entropy_decode(data, info, out=None):

@@ -71,3 +71,38 @@ def test_unsupported_files_are_refused():
         jpeg.entropy_decode(good, info, np.empty(10, np.int16))
     with pytest.raises(jo.Unsupported):
         jo.parse(_jpeg(rng, 40, 40, 2, 90, progressive=True))
+
+
+def test_damaged_files_never_crash_the_host_decoder():
+    """Truncated files, flipped bytes anywhere, overwritten scan data: parse() refuses, entropy_decode() raises or returns
+    (garbage) coefficients -- never a crash or a read past the buffer; a header claiming an absurd size is refused before any
+    buffer is sized from it."""
+    from face_vijnana_yolov3_amd import jpeg
+    rng = np.random.default_rng(5)
+    seen = {'decoded': 0, 'refused': 0, 'raised': 0}
+    for trial in range(150):
+        d = bytearray(_jpeg(rng, int(rng.integers(16, 120)), int(rng.integers(16, 120)), int(rng.integers(0, 3)), 85, ri=int(rng.integers(0, 2)) * 4))
+        if trial % 3 == 0:
+            d = d[:int(rng.integers(2, len(d)))]
+        elif trial % 3 == 1:
+            for _ in range(int(rng.integers(1, 8))):
+                d[int(rng.integers(0, len(d)))] = int(rng.integers(0, 256))
+        else:
+            i = int(rng.integers(len(d) // 2, len(d)))
+            d[i:i + 16] = bytes(rng.integers(0, 256, 16, dtype=np.uint8))
+        info = jpeg.parse(bytes(d))
+        if info is None:
+            seen['refused'] += 1
+            continue
+        assert info.width * info.height <= jpeg.MAX_PIXELS
+        try:
+            jpeg.entropy_decode(bytes(d), info, np.zeros(int(info.total_coefs), np.int16))
+            seen['decoded'] += 1
+        except ValueError:
+            seen['raised'] += 1
+    assert seen['refused'] > 0 and seen['decoded'] + seen['raised'] > 0, seen
+    # SOF0 with 65535 x 65535: 4.3 Gpixel
+    good = bytearray(_jpeg(rng, 32, 32, 2, 85))
+    k = good.find(b'\xff\xc0')
+    good[k + 5:k + 9] = b'\xff\xff\xff\xff'
+    assert jpeg.parse(bytes(good)) is None
