@@ -27,14 +27,13 @@ import glob
 import json
 import os
 import platform
-import shutil
 import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
 from . import data
-from .postproc import BoundBox, PinnedRing, decode_nms, letterbox_batch_device, letterbox_device, pack_images, to_boundboxes
+from .postproc import BoundBox, PinnedRing, decode_nms, letterbox_batch_device, pack_images, to_boundboxes
 
 DEBUG = True
 
