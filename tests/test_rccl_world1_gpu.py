@@ -69,6 +69,23 @@ for mode in ('plain', 'rccl'):
             torch.cuda.synchronize()
             rel = ((eng.grads - 0.5 * res[0][1]).norm() / (0.5 * res[0][1]).norm()).item()
             assert rel <= 1e-5, (cm, rel)
+        # the same check on the three-scale training step (fv_yolov3_train_step reports its ranges through the same protocol)
+        from face_vijnana_yolov3_amd.yolov3 import Yolov3
+        m3 = Yolov3(0, out_channels=18)
+        g3 = torch.Generator().manual_seed(5)
+        x3 = torch.rand((2, 96, 96, 3), generator=g3).cuda()
+        t3 = [torch.rand((2, 96 // d, 96 // d, 18), generator=g3).cuda() for d in (32, 16, 8)]
+        m3.init_synthetic(3); m3.ensure_optimizer()
+        m3.forward_backward(x3, t3)
+        torch.cuda.synchronize()
+        g_plain = m3.grads.clone()
+        for cm in ('wg', 'main'):
+            m3.init_synthetic(3); m3.iterations = 0; m3.grads = m3.m = m3.v = None
+            t4 = DataParallelTrainer(m3, world_size=1, rank=0, bucket_bytes=8 << 20, force_bucket_path=True, comm_mode=cm)
+            t4.train_on_batch(x3, t3, 1e-4, 0.9, 0.999, weight=0.5)
+            torch.cuda.synchronize()
+            rel = ((m3.grads - 0.5 * g_plain).norm() / (0.5 * g_plain).norm()).item()
+            assert rel <= 1e-5 and t4.collectives_launched >= 3, ('three-scale', cm, rel, t4.collectives_launched)
         tr.barrier()
         dist.destroy_process_group()
 # first step: same loss, same (all-reduced) gradient and first Adam moment up to the float-atomic order inside dW
