@@ -14,7 +14,8 @@ ratios.csv, the model files).  Differences, all documented in DESIGN.md:
     process without WORLD_SIZE trains on one GPU
   * evaluate() tolerates images without ground-truth rows and a missing arial.ttf
   * evaluate()/test() read ahead and run the network on batches of hps['eval_batch_size'] images (default 32; the
-    reference's loop is batch 1, fd.py:632-883) -- same rows in the same order
+    reference's loop is batch 1, fd.py:632-883) -- same rows in the same order (text-identical for the same head output; the
+    network's float32 summation order depends on the batch size, so scores may differ in the 7th digit between batch sizes)
   * train() and test() decode baseline JPEGs in two halves (jpeg.py): Huffman decoding on host threads, dequantisation / IDCT /
     chroma upsampling / colour conversion on the device, bit-identical to Pillow's pixels (hps['device_jpeg'] = false: Pillow);
     evaluate() draws on the image and keeps decoding it with Pillow

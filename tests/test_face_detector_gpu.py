@@ -206,3 +206,40 @@ def test_main_with_multi_gpu_starts_its_ranks_and_trains(tmp_path):
     ds, _ = hdf5_lite.read_hdf5(str(tmp_path / 'face_detector.h5'))
     assert int(np.asarray(ds['/fv/iterations']).reshape(-1)[0]) == 2          # 6 images, merged batch 3 (2 + 1 per rank), one epoch
     assert all(np.isfinite(v).all() for k, v in ds.items() if v.dtype.kind == 'f')
+
+
+@pytest.mark.parametrize('mode', ['evaluate', 'test'])
+def test_rows_do_not_depend_on_the_eval_batch_size_with_real_files(tmp_path, monkeypatch, mode):
+    """Seven real JPEGs through evaluate() (Pillow decode, pixels kept for drawing) and test() (host / device JPEG split): more
+    batches than the three reused pinned buffers, a short last batch, the two-deep device queue -- the csv holds the same rows at
+    eval_batch_size 1, 2 and 32 (text-identical for a fixed head output: test_csv_rows_match_the_reference_test_golden)."""
+    from face_vijnana_yolov3_amd import data
+    from face_vijnana_yolov3_amd.face_detection import FaceDetector
+    monkeypatch.chdir(tmp_path)
+    root = str(tmp_path / 'val'); os.makedirs(root)
+    data.make_synthetic_uccs(root, n_images=7, seed=4, csv_name='validation.csv')
+    texts = {}
+    fd = None
+    for bs in (1, 2, 32):
+        conf = _conf(root, mode)
+        conf['hps']['eval_batch_size'] = bs
+        conf['output_file_path'] = os.path.join(root, 'solution_%d.csv' % bs)
+        if fd is None:
+            fd = FaceDetector(conf)
+            d = fd.model.layers[-1]                                # a head of unit output scale that fires on some cells
+            y0 = fd.model.predict(np.random.default_rng(0).uniform(0, 1, (1, 416, 416, 3)).astype(np.float32))
+            fd.model.params[d['w_off']:d['beta_off']] /= float(y0.std())
+            fd.model.params[d['beta_off']] = 1.0; fd.model.params[d['beta_off'] + 5] = 1.0
+        fd.conf = conf; fd.hps = conf['hps']
+        getattr(fd, mode)()
+        texts[bs] = open(conf['output_file_path']).read()
+    # The network itself is not bit-identical across batch sizes (the K-split / tail plans of the conv launches, i.e. the fp32
+    # summation order, depend on the tile count), so: same files, same number of rows per file, same order, boxes equal up
+    # to one truncation step of the back-projection, scores to float32 rounding of the head.
+    rows = {bs: [ln.split(',') for ln in texts[bs].splitlines()] for bs in texts}
+    assert rows[1] and len({r[0] for r in rows[1]}) >= 2
+    for bs in (2, 32):
+        assert [r[0] for r in rows[bs]] == [r[0] for r in rows[1]], bs
+        a = np.array([[float(v) for v in r[1:]] for r in rows[bs]]); b = np.array([[float(v) for v in r[1:]] for r in rows[1]])
+        assert np.abs(a[:, :4] - b[:, :4]).max() <= 1e-6 * max(1.0, np.abs(b[:, :4]).max()), bs
+        assert np.abs(a[:, 4] - b[:, 4]).max() <= 2e-6, bs
