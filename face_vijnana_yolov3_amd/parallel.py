@@ -72,7 +72,8 @@ class DataParallelTrainer(object):
         #          range's weight-gradient kernels are in that stream's queue (fv_set_bucket_on_side) and a BLOCKING all_reduce is
         #          enqueued there -- it blocks the side stream only, the data-gradient chain on the compute stream runs on beside
         #          it and no event passes between the compute stream and the communication until the join at the end of the
-        #          backward pass.  Costs nothing at one rank (52.2 ms per step, as 'main'; tools/dp_trace.py);
+        #          backward pass.  Costs 0-0.4 ms per step at one rank (52.2 against 52.2, 52.1 against 52.0, 53.0 against 52.6 for
+        #          'main' on three boxes; tools/dp_trace.py, bench.py);
         #   'pg'   dist.all_reduce(async_op=True): the collective runs on the process group's OWN stream, ordered after the
         #          compute stream's work so far by the backend, and the compute stream waits for all of them before Adam -- the
         #          overlap with the rest of the backward pass without a second hop;
