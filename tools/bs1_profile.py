@@ -1,19 +1,25 @@
 import sys, torch
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from face_vijnana_yolov3_amd.engine import Engine
-eng = Engine(0); eng.init_synthetic(seed=7)
-x = torch.rand((1,416,416,3), device='cuda')
-for _ in range(5): eng.predict_device(x)
-torch.cuda.synchronize()
-e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(50): eng.predict_device(x)
-e1.record(); torch.cuda.synchronize()
-print('bs1 predict ms', e0.elapsed_time(e1)/50)
-eng.ctx.profile(True)
-for _ in range(10): eng.predict_device(x)
-p = eng.ctx.profile_collect(); eng.ctx.profile(False)
-tot=0
-for k,v in sorted(p.items(), key=lambda kv:-kv[1]['ms']):
-    print('%-34s launches/img %5.1f  ms/img %.4f  us/launch %.2f' % (k, v['launches']/10, v['ms']/10, v['ms']/v['launches']*1e3)); tot+=v['ms']/10
-print('sum of kernel ms/img', tot)
+
+def main():
+    import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from face_vijnana_yolov3_amd.engine import Engine
+    eng = Engine(0); eng.init_synthetic(seed=7)
+    x = torch.rand((1,416,416,3), device='cuda')
+    for _ in range(5): eng.predict_device(x)
+    torch.cuda.synchronize()
+    e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50): eng.predict_device(x)
+    e1.record(); torch.cuda.synchronize()
+    print('bs1 predict ms', e0.elapsed_time(e1)/50)
+    eng.ctx.profile(True)
+    for _ in range(10): eng.predict_device(x)
+    p = eng.ctx.profile_collect(); eng.ctx.profile(False)
+    tot=0
+    for k,v in sorted(p.items(), key=lambda kv:-kv[1]['ms']):
+        print('%-34s launches/img %5.1f  ms/img %.4f  us/launch %.2f' % (k, v['launches']/10, v['ms']/10, v['ms']/v['launches']*1e3)); tot+=v['ms']/10
+    print('sum of kernel ms/img', tot)
+
+
+if __name__ == '__main__':
+    main()
