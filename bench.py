@@ -524,7 +524,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    for _ in range(32):                             # comm_mode 'auto' (N > 1): the choice is made before the timed region
+    for _ in range(64):                             # comm_mode 'auto' (N > 1): the choice is made before the timed region
         if not trainer.calibrating:
             break
         step()

@@ -80,9 +80,10 @@ def _declare(L):
         'fv_state_count': (i64, []),
         'fv_workspace_bytes': (sz, [i32, i32, i32]),
         'fv_forward_infer': (i32, [vp, vp, vp, vp, i32, i32, vp, sz, vp]),
-        'fv_train_step': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, vp, BUCKET_FN, vp]),
+        'fv_train_step': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, vp, f64, BUCKET_FN, vp]),
         'fv_train_workspace_tensor': (i32, [i32, i32, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(i64)]),
         'fv_adam_step': (i32, [vp, vp, vp, vp, vp, i64, i64, f64, f64, f64, f64, f64]),
+        'fv_scale': (i32, [vp, vp, i64, f64]),
         'fv_conv2d_forward': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp]),
         'fv_conv2d_stat_rows': (i32, [i64]),
         'fv_conv2d_dgrad': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
@@ -110,7 +111,7 @@ def _declare(L):
         'fv_yolov3_workspace_bytes': (sz, [i32, i32, i32]),
         'fv_yolov3_forward': (i32, [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, vp, vp]),
         'fv_yolov3_train_workspace_bytes': (sz, [i32, i32, i32]),
-        'fv_yolov3_train_step': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, vp, BUCKET_FN, vp]),
+        'fv_yolov3_train_step': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, vp, f64, BUCKET_FN, vp]),
         'fv_yolov3_train_workspace_tensor': (i32, [i32, i32, i32, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(i64)]),
         'fv_yolo_decode_nms': (i32, [vp, vp, vp, vp, i32, i32, ctypes.POINTER(f32), f32, f64, i32, i32, i32, i32, i32,
                                      vp, vp, vp, vp]),
@@ -159,6 +160,10 @@ class Context:
     def side_stream(self):
         """hipStream_t of the library's side stream (int), for torch.cuda.ExternalStream."""
         return int(lib().fv_side_stream(self._h) or 0)
+
+    def scale(self, tensor, alpha):
+        """tensor *= alpha on the context's stream (fv_scale: the BN-state mean over the ranks of a data-parallel step)."""
+        self.check(lib().fv_scale(self._h, ptr(tensor), tensor.numel(), float(alpha)), 'fv_scale')
 
     def set_tail_split(self, on):
         self.check(lib().fv_set_tail_split(self._h, 1 if on else 0), 'fv_set_tail_split')

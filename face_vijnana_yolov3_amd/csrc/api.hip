@@ -46,7 +46,7 @@ FvProfScope::~FvProfScope() {
 
 extern "C" {
 
-int fv_abi_version(void) { return 1; }
+int fv_abi_version(void) { return 2; }   // 2: fv_train_step / fv_yolov3_train_step take loss_weight; fv_scale
 
 int fv_set_overlap(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;

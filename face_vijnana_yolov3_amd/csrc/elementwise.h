@@ -15,8 +15,9 @@ int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale
                  float* dz, double* slots = nullptr, int nslot = 0, bool reduced = false);
 // part != NULL: multi-workgroup form with fv_ew_mse_scratch_floats() floats of scratch (8-byte aligned); NULL: one workgroup
 int fv_ew_mse(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int Cpad, float* loss, float* dy, float* dbias,
-              double* part = nullptr);
+              double* part = nullptr, double grad_weight = 1.0);
 int fv_ew_mse_scratch_floats();
+int fv_ew_scale(fv_ctx* ctx, float* v, long long n, float alpha);
 int fv_ew_adam(fv_ctx* ctx, float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2, float eps);
 // training-mode BN without a finalize launch: the conv epilogue adds its column sums to
 // [nslot][2][C] fp64 accumulator slots (zeroed by the caller); this pass sums them, normalises, and
@@ -43,5 +44,6 @@ int fv_ew_upsample_concat_bwd(fv_ctx* ctx, const float* g, float* g_up, float* g
 int fv_ew_colsum_chunks(long long rows);
 int fv_ew_colsum(fv_ctx* ctx, const float* dy, long long rows, int C, int Cpad, double* part /*[chunks][C]*/, float* out);
 int fv_ew_yolo_loss_blocks(long long nbox);
-int fv_ew_yolo_loss_part(fv_ctx* ctx, const float* t, const float* y, long long cells, int ncls, int A, int Cpad, float* dy, double* part);
+int fv_ew_yolo_loss_part(fv_ctx* ctx, const float* t, const float* y, long long cells, int ncls, int A, int Cpad, float* dy, double* part,
+                         double grad_weight = 1.0);
 int fv_ew_yolo_loss_finish(fv_ctx* ctx, const double* part, const long long* cells3, int A, float* loss);

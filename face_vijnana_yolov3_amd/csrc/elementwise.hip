@@ -700,9 +700,11 @@ int fv_ew_bn_bwd(fv_ctx* ctx, const float* g, const float* z, const float* scale
 int fv_ew_mse_scratch_floats() { return 2 * MSE_G * 33; }
 
 int fv_ew_mse(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, int Cpad, float* loss, float* dy, float* dbias,
-              double* part) {
+              double* part, double grad_weight) {
     FV_REQUIRE(ctx, C <= 32 && Cpad >= C, "mse: C must be <= 32");
-    float gs = (float)(2.0 / ((double)rows * C));
+    // grad_weight: this rank's share n_r / N of a merged data-parallel batch -- it scales dy (and with it every gradient of the
+    // step, all linear in dy); the loss value stays this slice's own mean
+    float gs = (float)(2.0 * grad_weight / ((double)rows * C));
     if (part) {
         const int g = (rows + 7) / 8 < MSE_G ? (rows + 7) / 8 : MSE_G;
         hipLaunchKernelGGL(mse_part_kernel, dim3(g), dim3(256), 0, ctx->stream, yp, yt, rows, C, Cpad, gs, dy, part);
@@ -712,6 +714,18 @@ int fv_ew_mse(fv_ctx* ctx, const float* yp, const float* yt, int rows, int C, in
         return FV_OK;
     }
     hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, ctx->stream, yp, yt, rows, C, Cpad, gs, loss, dy, dbias);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ v, long long n, float alpha) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) v[i] *= alpha;
+}
+}  // namespace
+int fv_ew_scale(fv_ctx* ctx, float* v, long long n, float alpha) {
+    if (n <= 0) return FV_OK;
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, v, n, alpha);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }
@@ -893,12 +907,13 @@ __global__ void colsum_finish_kernel(const double* __restrict__ part, int nchunk
 // bce(t, y) = max(t, 0) - t*y + log1p(exp(-|t|));  scale loss = mean over cells x anchors.  dy = its gradient, zero padded.
 __device__ __forceinline__ double bce_logit(double t, double y) { return fmax(t, 0.0) - t * y + log1p(exp(-fabs(t))); }
 __global__ __launch_bounds__(256) void yolo_loss_part_kernel(const float* __restrict__ t, const float* __restrict__ y, long long nbox,
-                                                             int ncls, int A, int Cpad, float* __restrict__ dy, double* __restrict__ part) {
+                                                             int ncls, int A, int Cpad, double grad_weight, float* __restrict__ dy,
+                                                             double* __restrict__ part) {
     // one wave per (cell, anchor) box: lanes stride over the 5 + ncls entries, wave-reduce the box loss
     __shared__ double s_w[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int E = 5 + ncls;
-    const double gs = 1.0 / (3.0 * (double)nbox);
+    const double gs = grad_weight / (3.0 * (double)nbox);      // grad_weight: fv_ew_mse
     double acc = 0.0;
     for (long long bx = (long long)blockIdx.x * 4 + wave; bx < nbox; bx += (long long)gridDim.x * 4) {
         const long long cell = bx / A;
@@ -960,10 +975,11 @@ int fv_ew_colsum(fv_ctx* ctx, const float* dy, long long rows, int C, int Cpad, 
 }
 
 int fv_ew_yolo_loss_blocks(long long nbox) { long long n = (nbox + 3) / 4; return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n)); }
-int fv_ew_yolo_loss_part(fv_ctx* ctx, const float* t, const float* y, long long cells, int ncls, int A, int Cpad, float* dy, double* part) {
+int fv_ew_yolo_loss_part(fv_ctx* ctx, const float* t, const float* y, long long cells, int ncls, int A, int Cpad, float* dy, double* part,
+                         double grad_weight) {
     FV_REQUIRE(ctx, Cpad >= A * (5 + ncls), "yolo_loss: Cpad too small");
     const long long nbox = cells * A;
-    hipLaunchKernelGGL(yolo_loss_part_kernel, dim3(fv_ew_yolo_loss_blocks(nbox)), dim3(256), 0, ctx->stream, t, y, nbox, ncls, A, Cpad, dy, part);
+    hipLaunchKernelGGL(yolo_loss_part_kernel, dim3(fv_ew_yolo_loss_blocks(nbox)), dim3(256), 0, ctx->stream, t, y, nbox, ncls, A, Cpad, grad_weight, dy, part);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }

@@ -66,7 +66,8 @@ int parse(const uint8_t* b, size_t n, Parsed& P) {
     int adobe = -1;
     while (p + 4 <= n) {
         if (b[p] != 0xFF) return FV_ERR_INVALID;
-        while (p + 1 < n && b[p + 1] == 0xFF) ++p;
+        while (p + 1 < n && b[p + 1] == 0xFF) ++p;      // fill bytes
+        if (p + 2 > n) return FV_ERR_INVALID;             // the buffer ended inside a run of fill bytes: no marker code left
         const int m = b[p + 1];
         p += 2;
         if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;

@@ -286,10 +286,11 @@ int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, co
 }
 
 int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float* x, const float* y_true, int batch,
-                  int image_size, void* workspace, size_t workspace_bytes, float* grads, float* loss, fv_bucket_fn on_bucket,
-                  void* user) {
+                  int image_size, void* workspace, size_t workspace_bytes, float* grads, float* loss, double loss_weight,
+                  fv_bucket_fn on_bucket, void* user) {
     if (!ctx) return FV_ERR_INVALID;
     FV_REQUIRE(ctx, params && bn_state && x && y_true && workspace && grads && loss, "train_step: NULL buffer");
+    FV_REQUIRE(ctx, loss_weight > 0.0 && loss_weight <= 1.0, "train_step: loss_weight must be in (0, 1] (the slice's share of the merged batch)");
     if (int rc = check_shape(ctx, batch, image_size)) return rc;
     Plan p = make_plan(workspace, batch, image_size, true);
     if (p.bytes > workspace_bytes) return fv_fail(ctx, FV_ERR_WORKSPACE, "train_step: workspace %zu < %zu bytes", workspace_bytes, p.bytes);
@@ -347,10 +348,10 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
                                         params + h.beta_off, 0.f, nullptr, p.yhat, nullptr, nullptr)) return rc;
     }
     // ---------------- loss + its gradient (fd.py:381 'mse')
-    if (int rc = fv_ew_mse(ctx, p.yhat, y_true, hrows, HEAD_C, HEAD_PAD, loss, p.dyp, grads + h.beta_off, (double*)p.mse_part)) return rc;
+    if (int rc = fv_ew_mse(ctx, p.yhat, y_true, hrows, HEAD_C, HEAD_PAD, loss, p.dyp, grads + h.beta_off, (double*)p.mse_part,
+                          loss_weight)) return rc;
 
     // ---------------- backward
-    if (int rc = fv_op_conv_wgrad(ctx, p.a[nb - 1], p.dyp, batch, G, G, h.cin, h.cout, HEAD_PAD, 3, 1, grads + h.w_off)) return rc;
     // every data-gradient also reduces d-beta / d-gamma of the layer whose output gradient it produces (conv.h
     // FV_EPI_BNRED): the BN-backward of that layer then is the apply pass alone (measured for every layer, also the
     // 32/64-channel ones: fusing all of them 59.4 ms per step, none 61.0).
@@ -359,11 +360,11 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
         b = FvBnRed{p.z[l], p.scale[l], p.shift[l], p.mean[l], p.invstd[l], p.bslots[l], fv_ew_bn_stat_slots(d.cout), LEAKY};
         return &b;
     };
-    FvBnRed bnr;
-    if (int rc = fv_op_conv_dgrad(ctx, p.dyp, p.wt[nb], batch, G, G, h.cin, HEAD_PAD, 3, 1, nullptr, p.G[0], bnred(nb - 1, bnr))) return rc;
-    if (on_bucket) on_bucket(user, h.w_off, (int64_t)HEAD_C * 9 * 1024 + HEAD_C);
-    // a layer's gradient range is handed to the bucket callback once ev_wg[parity] of its weight-gradient (side stream) has been
-    // waited for
+    // A layer's gradient range is handed to the bucket callback once ev_wg[parity] of its weight-gradient (side stream) has been
+    // waited for -- or, with fv_set_bucket_on_side, as soon as that weight-gradient is in the side stream's queue (the callback
+    // then works on the side stream).  EVERY weight-gradient, the head's included, runs on the side stream: a range is never
+    // reported from a stream other than the one its gradient was made on (round 3 ran the head's on the compute stream and
+    // reported it at once: with a bucket smaller than the head's 221 KB a side-stream collective could have overtaken it).
     const bool ov = ctx->overlap && ctx->side;
     hipStream_t main_stream = ctx->stream;
     const bool early = ov && ctx->bucket_on_side;      // the callback fires at enqueue time and works on the side stream
@@ -375,6 +376,31 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
         pend[par].on = false;
         return FV_OK;
     };
+    // weight-gradient of layer l (dy rows of `ndy` floats) on the side stream behind ev_dz[par]; the range [off, off + cnt) is its
+    // kernel + (gamma, beta | bias).  ev_wg[par] is recorded BEFORE an early callback: it guards the reuse of the dz buffer, which
+    // needs the weight-gradient alone -- recorded after the callback it would make the compute stream wait for the collective the
+    // callback enqueued (the host joins the side stream once, before Adam).
+    auto wgrad_side = [&](int par, const float* xin, const float* dyv, int H, const fv_layer_desc& d, int ndy, int64_t off, int64_t cnt) -> int {
+        if (!ov) {
+            if (int rc = fv_op_conv_wgrad(ctx, xin, dyv, batch, H, H, d.cin, d.cout, ndy, d.ksize, d.stride, grads + d.w_off)) return rc;
+            if (on_bucket) on_bucket(user, off, cnt);
+            return FV_OK;
+        }
+        FV_HIP(ctx, hipEventRecord(ctx->ev_dz[par], main_stream));
+        FV_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_dz[par], 0));
+        ctx->stream = ctx->side;
+        const int rc = fv_op_conv_wgrad(ctx, xin, dyv, batch, H, H, d.cin, d.cout, ndy, d.ksize, d.stride, grads + d.w_off);
+        ctx->stream = main_stream;
+        if (rc) return rc;
+        FV_HIP(ctx, hipEventRecord(ctx->ev_wg[par], ctx->side));
+        if (early && on_bucket) on_bucket(user, off, cnt);      // may enqueue a collective on the side stream
+        pend[par] = Pending{true, off, cnt};
+        return FV_OK;
+    };
+    // head: its bias gradient was written by the loss kernel above (compute stream, before ev_dz is recorded)
+    if (int rc = wgrad_side(nb & 1, p.a[nb - 1], p.dyp, G, h, HEAD_PAD, h.w_off, (int64_t)HEAD_C * 9 * 1024 + HEAD_C)) return rc;
+    FvBnRed bnr;
+    if (int rc = fv_op_conv_dgrad(ctx, p.dyp, p.wt[nb], batch, G, G, h.cin, HEAD_PAD, 3, 1, nullptr, p.G[0], bnred(nb - 1, bnr))) return rc;
     {
     // G[ig]: gradient w.r.t. the current layer's (post-add) output; G[ires]: kept block gradient.
     // dz(l) -> D[l&1].  The weight-gradient of layer l only needs dz(l) and the saved forward
@@ -395,20 +421,7 @@ int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float
                                   true)) return rc;
         const float* xin = l == 0 ? x : p.a[l - 1];
         const int64_t cnt = (int64_t)d.cout * d.ksize * d.ksize * d.cin + 2 * d.cout;
-        if (ov) {
-            FV_HIP(ctx, hipEventRecord(ctx->ev_dz[par], main_stream));
-            FV_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_dz[par], 0));
-            ctx->stream = ctx->side;
-            int rc = fv_op_conv_wgrad(ctx, xin, dz, batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off);
-            ctx->stream = main_stream;
-            if (rc) return rc;
-            if (early && on_bucket) on_bucket(user, d.w_off, cnt);      // may enqueue a collective on the side stream
-            FV_HIP(ctx, hipEventRecord(ctx->ev_wg[par], ctx->side));
-            pend[par] = Pending{true, d.w_off, cnt};
-        } else {
-            if (int rc = fv_op_conv_wgrad(ctx, xin, dz, batch, H, H, d.cin, d.cout, d.cout, d.ksize, d.stride, grads + d.w_off)) return rc;
-            if (on_bucket) on_bucket(user, d.w_off, cnt);
-        }
+        if (int rc = wgrad_side(par, xin, dz, H, d, d.cout, d.w_off, cnt)) return rc;
         if (l == 0) break;
         // dgrad overwrites the consumed gradient buffer G[ig] unless that is the kept block gradient
         const int iout = (ig == ires) ? 1 - ig : ig;

@@ -338,8 +338,9 @@ int fv_yolov3_train_workspace_tensor(int batch, int image_size, int out_channels
 
 int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float* x, const float* yt13, const float* yt26,
                          const float* yt52, int batch, int image_size, int out_channels, void* workspace, size_t workspace_bytes,
-                         float* grads, float* loss, fv_bucket_fn on_bucket, void* user) {
+                         float* grads, float* loss, double loss_weight, fv_bucket_fn on_bucket, void* user) {
     if (!ctx) return FV_ERR_INVALID;
+    FV_REQUIRE(ctx, loss_weight > 0.0 && loss_weight <= 1.0, "yolov3_train_step: loss_weight must be in (0, 1]");
     FV_REQUIRE(ctx, params && bn_state && x && yt13 && yt26 && yt52 && workspace && grads && loss, "yolov3_train_step: NULL buffer");
     FV_REQUIRE(ctx, batch >= 1 && image_size >= 32 && image_size % 32 == 0 && out_channels >= 18 && out_channels % 3 == 0,
                "yolov3_train_step: bad shape (out_channels = 3*(5+classes))");
@@ -418,7 +419,7 @@ int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, cons
         int off = 0;
         for (int s = 0; s < 3; ++s) {
             cells[s] = (long long)B * (S / (32 >> s)) * (S / (32 >> s));
-            if (int rc = fv_ew_yolo_loss_part(ctx, p.y[s], yt[s], cells[s], ncls, 3, p.cpad, p.dy[s], lpart + off)) return rc;
+            if (int rc = fv_ew_yolo_loss_part(ctx, p.y[s], yt[s], cells[s], ncls, 3, p.cpad, p.dy[s], lpart + off, loss_weight)) return rc;
             off += fv_ew_yolo_loss_blocks(cells[s] * 3);
             if (int rc = fv_ew_colsum(ctx, p.dy[s], cells[s], out_channels, p.cpad, (double*)p.colsum_part, grads + N.L[det[s]].d.beta_off)) return rc;
         }
@@ -465,8 +466,10 @@ int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, cons
         const int rc = fv_op_conv_wgrad(ctx, xin, dyv, B, H, H, d.cin, d.cout, ndy, d.ksize, d.stride, dw);
         ctx->stream = main_stream;
         if (rc) return rc;
-        if (early && on_bucket) on_bucket(user, d.w_off, cnt);      // may enqueue a collective on the side stream
+        // recorded BEFORE an early callback: the event guards the reuse of the dz buffer, which needs the weight-gradient alone
+        // (after the callback it would make the compute stream wait for the collective the callback enqueued; net.hip)
         FV_HIP(ctx, hipEventRecord(ctx->ev_wg[s], ctx->side));
+        if (early && on_bucket) on_bucket(user, d.w_off, cnt);      // may enqueue a collective on the side stream
         pend[s] = Pending{true, d.w_off, cnt};
         return FV_OK;
     };

@@ -232,4 +232,10 @@ int fv_adam_step(fv_ctx* ctx, float* params, const float* grads, float* m, float
     return fv_ew_adam(ctx, params, grads, m, v, n, (float)lr_t, (float)beta_1, (float)beta_2, (float)eps);
 }
 
+int fv_scale(fv_ctx* ctx, float* v, int64_t n, double alpha) {
+    if (!ctx) return FV_ERR_INVALID;
+    FV_REQUIRE(ctx, v && n >= 0, "scale: NULL buffer");
+    return fv_ew_scale(ctx, v, n, (float)alpha);
+}
+
 }  // extern "C"

@@ -117,9 +117,10 @@ class Engine(object):
             self.m = torch.zeros_like(self.params)
             self.v = torch.zeros_like(self.params)
 
-    def forward_backward(self, x, y_true, on_bucket=None):
+    def forward_backward(self, x, y_true, on_bucket=None, loss_weight=1.0):
         """fwd + mse + bwd; gradients land in self.grads; returns the loss as a 1-element CUDA
-        tensor (no host sync).  on_bucket(offset, count) is called as gradient ranges complete."""
+        tensor (no host sync).  on_bucket(offset, count) is called as gradient ranges complete.
+        loss_weight: this slice's share n_r / N of a merged data-parallel batch (fv_train_step): scales the gradients, not the loss."""
         self.ensure_optimizer()
         x = self._as_input(x)
         y_true = self._as_input(y_true)
@@ -143,7 +144,7 @@ class Engine(object):
         self._bucket_cb = cb  # keep alive during the call
         self.ctx.set_bn_zero_debias_step(self.bn_updates + 1 if self.bn_zero_debias else 0)
         rc = lib().fv_train_step(self.ctx.handle, ptr(self.params), ptr(self.state), ptr(x), ptr(y_true), B, S, ptr(ws),
-                                 ws.numel(), ptr(self.grads), ptr(self._loss), cb, None)
+                                 ws.numel(), ptr(self.grads), ptr(self._loss), float(loss_weight), cb, None)
         self.ctx.check(rc, 'fv_train_step')
         if cb_error:
             raise cb_error[0]

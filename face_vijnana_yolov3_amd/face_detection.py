@@ -280,9 +280,14 @@ class FaceDetector(object):
                         plan = jpeg.BatchPlan(infos)
                         buf = ring.take(2 * plan.total_coefs).view(torch.int16)     # decoded straight into a reused pinned buffer
                         view = buf.numpy()
-                        list(pool.map(lambda i: jpeg.entropy_decode(datas[i], infos[i], view[plan.coef_off[i]:plan.coef_off[i] + int(infos[i].total_coefs)]),
-                                      range(len(chunk))))
-                        return None, ('jpeg', buf, plan)
+                        try:
+                            list(pool.map(lambda i: jpeg.entropy_decode(datas[i], infos[i], view[plan.coef_off[i]:plan.coef_off[i] + int(infos[i].total_coefs)]),
+                                          range(len(chunk))))
+                            return None, ('jpeg', buf, plan)
+                        except ValueError:
+                            # damaged scan data (a bad Huffman code, a run past the block): libjpeg -- the reference's reader
+                            # (skimage.io.imread, fd.py:798) -- only warns and returns an image; so the batch goes through Pillow
+                            ring.untake()
                 raws = list(pool.map(data._pil_loader, chunk))
                 return raws, pack_images(raws, ring=ring)
             def finish(done):
@@ -405,8 +410,14 @@ class BatchFeeder(object):
         else:
             buf = torch.empty(plan.total_coefs, dtype=torch.int16)
         view = buf.numpy()
-        list(self.pool.map(lambda i: jpeg.entropy_decode(datas[i], infos[i], view[plan.coef_off[i]:plan.coef_off[i] + int(infos[i].total_coefs)]),
-                           range(len(names))))
+        try:
+            list(self.pool.map(lambda i: jpeg.entropy_decode(datas[i], infos[i], view[plan.coef_off[i]:plan.coef_off[i] + int(infos[i].total_coefs)]),
+                               range(len(names))))
+        except ValueError:
+            # damaged scan data: libjpeg (the reference's reader, fd.py:112) warns and still returns an image -- Pillow path
+            if slot is not None:
+                self.ring.untake()
+            return None
         return ('jpeg', buf, plan), [(i.height, i.width) for i in infos], slot
 
     def copied(self, slot):

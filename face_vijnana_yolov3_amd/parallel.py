@@ -5,16 +5,22 @@ the full model on its 40-image slice with PER-RANK BatchNorm statistics (= the r
 per-tower statistics), the loss is the mean over the merged batch, so the gradient is the mean of
 the per-rank gradients.  Gradients live in one flat fp32 vector; as the backward pass finishes a
 layer the C ABI reports its range (fv_bucket_fn) and ranges are coalesced into buckets of
->= bucket_bytes that are all-reduced asynchronously (on the process group's own stream) while backward
-continues; the compute stream waits for them before Adam.  xGMI is
+>= bucket_bytes that are all-reduced while backward continues.  Where the collectives run is
+`comm_mode` (FV_COMM_STREAM): the default 'auto' starts in 'wg' -- a blocking all_reduce enqueued on
+the library's weight-gradient stream, right behind the kernels that made the bucket, beside the
+data-gradient chain on the compute stream -- and keeps it unless a measurement over the first steps
+of the job shows another mode more than 1 % faster (DataParallelTrainer below).  The compute stream
+joins the communication once per step, before Adam.  xGMI is
 point-to-point, so few large collectives beat many small ones: default bucket 32 MiB
 (162.56 MB of gradients -> 5-6 collectives per step).  Adam then runs redundantly on every rank
 (bit-identical weights, no broadcast).
 
 Uneven slices (multi_gpu_model gives the remainder of a short last batch to the last tower): the
-merged-batch MSE is sum_r n_r/N * loss_r, so every rank scales its gradient by n_r/N before the SUM
-all-reduce; a batch with fewer images than ranks is skipped on ALL ranks (`slice_batch` returns None
-everywhere), never on some -- a rank that stayed out of a collective would hang the others."""
+merged-batch MSE is sum_r n_r/N * loss_r, so every rank hands its share n_r/N to the step as
+`loss_weight` (fv_train_step scales dL/dy with it in the loss kernel: the gradients arrive pre-scaled,
+no pass over the 162 MB vector) and the ranks SUM; a batch with fewer images than ranks is skipped on
+ALL ranks (`slice_batch` returns None everywhere), never on some -- a rank that stayed out of a
+collective would hang the others."""
 import os
 import shutil
 
@@ -83,15 +89,19 @@ class DataParallelTrainer(object):
         # Measured on one MI355X with a world-size-1 nccl group (no RCCL kernel runs there: the stream / event traffic alone;
         # tools/dp_overhead2.py, tools/dp_trace.py; plain step 52.2 ms): 'wg' 52.2, 'main' 52.2, 'pg' 55.6, 'side' the same as
         # 'pg' (worse at high priority or with GPU_MAX_HW_QUEUES=8), independent of the number of buckets.
-        #   'auto' (default) the first AUTO_WARM + 2 * AUTO_STEPS + 1 optimisation steps time 'wg' and then 'main' (max over ranks,
-        #          so every rank decides alike) and the faster one is kept -- self.auto_report says what was measured.
+        #   'auto' (default) starts in 'wg'.  With more than one rank the first steps of the job time 'wg', 'main' and 'pg' over
+        #          AUTO_STEPS steps each (max over ranks, so every rank decides alike) and 'wg' is kept unless another mode is
+        #          more than 1 % faster -- self.auto_report says what was measured.  At one rank there is nothing to overlap
+        #          (RCCL launches no kernel for a one-rank all-reduce) and no contest: 'wg'.
         # 'pg' / 'side' put 60 us bubbles in front of two dozen kernels of the backward pass and stretch the rest (rocprofv3
-        # timeline of tools/dp_trace.py: 55.6 against 52.2 ms per step at one rank); kept selectable for comparison.
+        # timeline of tools/dp_trace.py: 55.6 against 52.2 ms per step at one rank); whether real communication time hidden on a
+        # third stream is worth that on a node is what the calibration decides.
         self.comm_mode = comm_mode or os.environ.get('FV_COMM_STREAM', 'auto')
         if self.comm_mode not in ('pg', 'side', 'main', 'auto', 'wg'):
             raise ValueError("FV_COMM_STREAM must be 'auto', 'wg', 'pg', 'side' or 'main'")
         self.auto_report = None
         self._auto_k = None
+        self._auto_ms = []
         if self.comm_mode == 'auto':
             self.comm_mode = 'wg'
             # resolved in train_on_batch (needs a process group to be worth measuring); a trainer without the bucket path has
@@ -102,6 +112,8 @@ class DataParallelTrainer(object):
         if self.bucketed:
             if self.comm_mode == 'side':
                 self.comm = torch.cuda.Stream(device=engine.dev, priority=int(os.environ.get('FV_COMM_PRIORITY', '0')))
+            if not engine.ctx.side_stream():
+                raise RuntimeError('the context has no side stream: comm_mode wg needs fv_side_stream(ctx)')
             self.wg_stream = torch.cuda.ExternalStream(engine.ctx.side_stream(), device=engine.dev)
             engine.ensure_optimizer()
             self.reducer = BucketReducer(engine.grads, self.world, bucket_bytes, self._launch)
@@ -127,63 +139,77 @@ class DataParallelTrainer(object):
             dist.broadcast(engine.state, 0)
 
     def _launch(self, view):
-        """One bucket: scale by n_rank / n_total (SUM over ranks = gradient of the merged-batch mean), all-reduce."""
-        if self.comm_mode == 'wg' and self.eng.ctx.overlap:      # without the overlap the library reports ranges on its own stream
+        """One bucket: all-reduce(SUM).  The gradients arrive scaled by n_rank / n_total (loss_weight of the step), so the
+        sum over the ranks is the gradient of the merged-batch mean."""
+        if self.comm_mode == 'wg':
+            # the range was reported from the side stream's queue (fv_set_bucket_on_side): its weight-gradient kernels are ahead
+            # of anything enqueued there now.  Without the overlap the library reports ranges on the compute stream itself.
+            if not self.eng.ctx.overlap:
+                return self._collective(view)
             with torch.cuda.stream(self.wg_stream):
-                if self._weight != 1.0:
-                    view.mul_(self._weight)
-                if self.collective:
-                    dist.all_reduce(view, op=dist.ReduceOp.SUM)      # blocking for the SIDE stream only
-                    self.collectives_launched += 1
+                self._collective(view)      # blocking for the SIDE stream only
             return
         if self.comm_mode == 'side':
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.eng.dev))
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(ev)
-                if self._weight != 1.0:
-                    view.mul_(self._weight)
-                if self.collective:
-                    dist.all_reduce(view, op=dist.ReduceOp.SUM)
-                    self.collectives_launched += 1
+                self._collective(view)
             return
-        if self._weight != 1.0:
-            view.mul_(self._weight)
-        if self.collective:
-            if self.comm_mode == 'pg':
-                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
-            else:
-                dist.all_reduce(view, op=dist.ReduceOp.SUM)
-            self.collectives_launched += 1
+        self._collective(view, async_op=self.comm_mode == 'pg')
 
-    _weight = 1.0
-    AUTO_WARM, AUTO_STEPS = 3, 4
+    _probe = None      # test hook: called with the bucket view at the point of the collective, on the stream the collective uses
+
+    def _collective(self, view, async_op=False):
+        if self._probe is not None:
+            self._probe(view)
+        if not self.collective:
+            return
+        if async_op:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM)
+        self.collectives_launched += 1
+
+    AUTO_WARM, AUTO_STEPS = 3, 8
+    AUTO_MODES = ('wg', 'main', 'pg')
+    AUTO_MARGIN = 0.01       # 'wg' is kept unless another mode is more than this fraction faster
 
     def _auto_tick(self):
-        """comm_mode 'auto': called at the top of every step until decided.  Steps [0, W) warm up in 'wg', [W, W+S) time 'wg',
-        step W+S warms 'main', [W+S+1, W+2S+1) time 'main'; at step W+2S+1 the two times are max-reduced over the ranks and the
-        faster mode is kept.  Three host synchronisations in all; every step of the calibration is an ordinary training step."""
+        """comm_mode 'auto': called at the top of every step until decided.  AUTO_WARM steps warm up in 'wg'; then every mode
+        of AUTO_MODES in turn runs one untimed step and AUTO_STEPS timed ones (host clock around a device synchronisation);
+        the times are max-reduced over the ranks and 'wg' is kept unless another mode beats it by more than AUTO_MARGIN.
+        Every step of the calibration is an ordinary training step.  One rank: no contest, 'wg'."""
         import time
-        W, S, k = self.AUTO_WARM, self.AUTO_STEPS, self._auto_k
         if not self.collective:                  # nothing to overlap without a group
             self.comm_mode, self._auto_k = 'main', None
             return
-        if k in (W, W + S, W + S + 1, W + 2 * S + 1):
-            torch.cuda.synchronize(self.eng.dev)
-            now = time.perf_counter()
-            if k == W + S:
-                self._auto_pg = (now - self._auto_t0) / S * 1e3
-                self.comm_mode = 'main'
-            elif k == W + 2 * S + 1:
-                t = torch.tensor([self._auto_pg, (now - self._auto_t0) / S * 1e3], dtype=torch.float64, device=self.eng.dev)
+        if self.world == 1:
+            self.comm_mode, self._auto_k = 'wg', None
+            self.auto_report = dict(chosen='wg', skipped='one rank: RCCL runs no kernel for a one-rank all-reduce, nothing to compare')
+            return
+        W, S, k = self.AUTO_WARM, self.AUTO_STEPS, self._auto_k
+        per = S + 1                               # steps per mode: one warm-up + S timed
+        if k >= W:
+            j, r = divmod(k - W, per)
+            if r == 0 and j > 0:                  # mode j-1 has run its S timed steps
+                torch.cuda.synchronize(self.eng.dev)
+                self._auto_ms.append((time.perf_counter() - self._auto_t0) / S * 1e3)
+            if r == 0 and j == len(self.AUTO_MODES):
+                t = torch.tensor(self._auto_ms, dtype=torch.float64, device=self.eng.dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                wg_ms, main_ms = (float(v) for v in t.cpu())
-                self.comm_mode = 'wg' if wg_ms < main_ms else 'main'
-                self.auto_report = dict(wg_ms_per_step=round(wg_ms, 3), main_ms_per_step=round(main_ms, 3), chosen=self.comm_mode,
-                                        steps_each=S)
+                ms = dict(zip(self.AUTO_MODES, (float(v) for v in t.cpu())))
+                best = min(ms, key=ms.get)
+                self.comm_mode = best if ms[best] < ms['wg'] * (1.0 - self.AUTO_MARGIN) else 'wg'
+                self.auto_report = dict(ms_per_step={m: round(v, 3) for m, v in ms.items()}, chosen=self.comm_mode, steps_each=S,
+                                        rule="'wg' unless another mode is more than %g %% faster" % (100 * self.AUTO_MARGIN))
                 self._auto_k = None
                 return
-            self._auto_t0 = now
+            if r == 0:
+                self.comm_mode = self.AUTO_MODES[j]
+            elif r == 1:
+                torch.cuda.synchronize(self.eng.dev)
+                self._auto_t0 = time.perf_counter()
         self._auto_k = k + 1
 
     @property
@@ -203,7 +229,7 @@ class DataParallelTrainer(object):
         for lo, hi in self.reducer.launched:
             dist.all_reduce(self.eng.grads[lo:hi], op=dist.ReduceOp.SUM)
         dist.all_reduce(self.eng.state, op=dist.ReduceOp.SUM)
-        self.eng.state.mul_(1.0 / self.world)
+        self.eng.ctx.scale(self.eng.state, 1.0 / self.world)
         e1.record(); torch.cuda.synchronize(self.eng.dev)
         return e0.elapsed_time(e1)
 
@@ -215,24 +241,28 @@ class DataParallelTrainer(object):
         if self._auto_k is not None:
             self._auto_tick()
         self._weight = float(weight) if weight is not None else 1.0 / self.world
-        eng.ctx.set_bucket_on_side(self.comm_mode == 'wg')       # per step: several trainers may share one context
+        on_side = self.comm_mode == 'wg' and eng.ctx.overlap
+        eng.ctx.set_bucket_on_side(on_side)       # per step: several trainers may share one context
         self.reducer.reset()
-        loss = eng.forward_backward(x, y, on_bucket=self.reducer.on_range)
+        try:
+            loss = eng.forward_backward(x, y, on_bucket=self.reducer.on_range, loss_weight=self._weight)
+        finally:
+            eng.ctx.set_bucket_on_side(False)     # a later direct forward_backward(on_bucket=...) gets stream-ordered callbacks again
         self.reducer.flush()
-        if self.comm_mode == 'wg' and eng.ctx.overlap:       # the last bucket went out after fv_train_step had joined the side stream
-            torch.cuda.current_stream(eng.dev).wait_stream(self.wg_stream)
+        main = torch.cuda.current_stream(eng.dev)
         # BN moving statistics: the reference's towers race on shared variables (undefined order); we keep ranks identical
-        # by averaging (parity unpinned)
+        # by averaging (parity unpinned): SUM over the ranks, then fv_scale by 1 / world on the compute stream
         if self.comm_mode == 'side':
             with torch.cuda.stream(self.comm):
-                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(eng.dev))
+                ev = torch.cuda.Event(); ev.record(main)
                 self.comm.wait_event(ev)
                 if self.collective:
                     dist.all_reduce(eng.state, op=dist.ReduceOp.SUM)
                     self.collectives_launched += 1
-                eng.state.mul_(1.0 / self.world)
-            torch.cuda.current_stream(eng.dev).wait_stream(self.comm)
+            main.wait_stream(self.comm)
         else:
+            if on_side:       # the last bucket went out after the step had joined the side stream: join it again
+                main.wait_stream(self.wg_stream)
             if self.collective:
                 if self.comm_mode == 'pg':
                     self._works.append(dist.all_reduce(eng.state, op=dist.ReduceOp.SUM, async_op=True))
@@ -242,7 +272,8 @@ class DataParallelTrainer(object):
             for w in self._works:           # the compute stream waits for every collective of this step (no host wait with nccl)
                 w.wait()
             self._works = []
-            eng.state.mul_(1.0 / self.world)
+        if self.world > 1:
+            eng.ctx.scale(eng.state, 1.0 / self.world)
         eng.adam_step(lr, beta_1, beta_2, decay)
         return loss
 

@@ -110,6 +110,10 @@ class PinnedRing(object):
             self._pins[i] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
         return self._pins[i][:nbytes]
 
+    def untake(self):
+        """The buffer of the last take() will not be used after all: the next take() hands out the same slot again."""
+        self._next = (self._next - 1) % len(self._pins)
+
     def copied(self, buf):
         """An event on the current stream guards the slot `buf` (any view of it) came from."""
         import torch

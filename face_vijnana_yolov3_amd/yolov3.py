@@ -113,7 +113,7 @@ class Yolov3(object):
         if self.grads is None:
             self.grads = torch.zeros_like(self.params); self.m = torch.zeros_like(self.params); self.v = torch.zeros_like(self.params)
 
-    def forward_backward(self, x, targets, on_bucket=None):
+    def forward_backward(self, x, targets, on_bucket=None, loss_weight=1.0):
         """x (B,S,S,3); targets: three tensors shaped like the outputs, (B,g,g,3*(5+classes)).  Gradients land in
         self.grads; returns the loss (1-element CUDA tensor).  on_bucket(offset, count): called as gradient ranges complete
         (descending offsets), the protocol of Engine.forward_backward -- parallel.DataParallelTrainer drives either."""
@@ -139,7 +139,7 @@ class Yolov3(object):
         self._bucket_cb = cb
         self.ctx.set_bn_zero_debias_step(self.bn_updates + 1 if self.bn_zero_debias else 0)
         rc = lib().fv_yolov3_train_step(self.ctx.handle, ptr(self.params), ptr(self.state), ptr(x), ptr(t[0]), ptr(t[1]), ptr(t[2]), B, S,
-                                        self.out_channels, ptr(ws), ws.numel(), ptr(self.grads), ptr(self._loss), cb, None)
+                                        self.out_channels, ptr(ws), ws.numel(), ptr(self.grads), ptr(self._loss), float(loss_weight), cb, None)
         self.ctx.check(rc, 'fv_yolov3_train_step')
         if cb_error:
             raise cb_error[0]

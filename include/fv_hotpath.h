@@ -171,12 +171,16 @@ typedef void (*fv_bucket_fn)(void* user, int64_t offset, int64_t count);
  * (batch statistics, moving statistics updated in bn_state), mean-squared error over every element
  * of [batch][G][G][6], gradients of all 40 640 230 parameters written to `grads` (overwritten).
  * loss: one float (device).  Follow with fv_adam_step.
+ * loss_weight: 1 for a single-GPU step.  Data parallel (keras.utils.multi_gpu_model, fd.py:358-371: ONE loss over the
+ * concatenated tower outputs): the share n_rank / n_total of the merged batch this call's slice holds -- it scales dL/dy in the
+ * loss kernel, so every gradient of the step arrives pre-scaled and the SUM all-reduce over the ranks yields the gradient of
+ * the merged-batch mean without a separate scaling pass over the 162 MB vector; `loss` stays this slice's own mean.
  * Reproducibility: kernel gradients are accumulated with float atomics and the BN statistics with fp64
  * atomics, so two runs agree to rounding (dW ~3e-6 relative, statistics in the last float bit at most),
  * not bit for bit; fv_forward_infer is bit-reproducible. */
 int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float* x, const float* y_true,
                   int batch, int image_size, void* workspace, size_t workspace_bytes, float* grads,
-                  float* loss, fv_bucket_fn on_bucket, void* user);
+                  float* loss, double loss_weight, fv_bucket_fn on_bucket, void* user);
 
 /* Introspection of the training workspace after fv_train_step (test aid; Keras keeps these tensors
  * inside the TF graph): where layer `layer` (0..51) keeps which = 0 pre-BN output z, 1 activated output a
@@ -192,6 +196,10 @@ int fv_train_workspace_tensor(int batch, int image_size, int layer, int which, s
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m / (sqrt(v) + eps)  (eps = 1e-7). */
 int fv_adam_step(fv_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n,
                  int64_t iteration, double lr, double beta_1, double beta_2, double eps, double decay);
+/* v[i] *= alpha over n floats on the context's stream.  The data-parallel host uses it for the one small vector whose mean over
+ * the ranks is not a gradient: the 35 712 BN moving statistics after their SUM all-reduce (the reference's towers race on
+ * shared variables, fd.py:369 -- SURVEY 8e; the build keeps the ranks identical by averaging). */
+int fv_scale(fv_ctx* ctx, float* v, int64_t n, double alpha);
 
 /* ------------------------------------------------------------------ hot path: single operators
  * (what the network-level calls are built from; exported for unit parity tests) */
@@ -332,13 +340,14 @@ int fv_yolov3_forward(fv_ctx* ctx, const float* params, const float* bn_state, c
  *     ( bce(t4, y4) + mean_{k<4} |t_k - y_k| + mean_c bce(t_{5+c}, y_{5+c}) ) / 3
  * -- the reference's fd_loss (fd.py:59-64) generalised to 3 anchors and `classes` classes, with the
  * cross-entropies on logits: bce(t, y) = max(t,0) - t*y + log1p(exp(-|t|)).  Follow with fv_adam_step.
+ * loss_weight: as in fv_train_step (scales the gradient, not the reported loss).
  * on_bucket (may be NULL): as in fv_train_step -- called on the host as the gradient range of a layer completes, in reverse
  * execution order = descending offsets, contiguous, covering every parameter once (data-parallel overlap of the all-reduce). */
 size_t fv_yolov3_train_workspace_bytes(int batch, int image_size, int out_channels);
 int fv_yolov3_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float* x, const float* yt13,
                          const float* yt26, const float* yt52, int batch, int image_size, int out_channels,
-                         void* workspace, size_t workspace_bytes, float* grads, float* loss, fv_bucket_fn on_bucket,
-                         void* user);
+                         void* workspace, size_t workspace_bytes, float* grads, float* loss, double loss_weight,
+                         fv_bucket_fn on_bucket, void* user);
 /* as fv_train_workspace_tensor, for the workspace of fv_yolov3_train_step (BN layers of fv_yolov3_layer) */
 int fv_yolov3_train_workspace_tensor(int batch, int image_size, int out_channels, int layer, int which,
                                      size_t* offset_bytes, int64_t* count);

@@ -106,3 +106,97 @@ def test_damaged_files_never_crash_the_host_decoder():
     k = good.find(b'\xff\xc0')
     good[k + 5:k + 9] = b'\xff\xff\xff\xff'
     assert jpeg.parse(bytes(good)) is None
+
+
+def _flush_against_guard_page(data):
+    """-> (pointer, keepalive): `data` copied so that its last byte is the last byte of a readable page and the next page is
+    PROT_NONE -- a read one byte past the buffer faults instead of passing unnoticed (the CPU build's stand-in for ASan)."""
+    import ctypes
+    import mmap
+    page = mmap.PAGESIZE
+    npages = (len(data) + page - 1) // page + 1
+    mm = mmap.mmap(-1, npages * page, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS, prot=mmap.PROT_READ | mmap.PROT_WRITE)
+    base = ctypes.addressof(ctypes.c_char.from_buffer(mm))
+    libc = ctypes.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert libc.mprotect(base + (npages - 1) * page, page, 0) == 0          # PROT_NONE
+    start = (npages - 1) * page - len(data)
+    mm[start:start + len(data)] = data
+    return base + start, mm
+
+
+def test_parser_never_reads_past_the_buffer():
+    """the fill-byte loop of parse() could read b[n] when a file ends in a run of 0xFF.  Every prefix of a real header
+    and every tail of fill bytes is parsed flush against a PROT_NONE page."""
+    import ctypes
+    from face_vijnana_yolov3_amd import jpeg
+    L = jpeg._fn()
+    good = _jpeg(np.random.default_rng(11), 40, 56, 2, 90, ri=2)
+    sos = good.find(b'\xff\xda')
+    cases = [good[:k] for k in range(0, sos + 16)]
+    cases += [b'\xff\xd8' + b'\xff' * k for k in range(0, 12)]
+    cases += [good[:k] + b'\xff' * t for k in (2, 4, 20, 21, sos, sos + 2) for t in (1, 2, 3, 7)]
+    for d in cases:
+        if not d:
+            continue
+        p, keep = _flush_against_guard_page(d)
+        info = jpeg.JpegInfo()
+        rc = L.fv_jpeg_parse(ctypes.c_void_p(p), len(d), ctypes.byref(info))
+        assert rc != 0 or len(d) > sos, (len(d), rc)
+        del keep
+    p, keep = _flush_against_guard_page(good)                      # the whole file, headers + scan, both entry points
+    info = jpeg.JpegInfo()
+    assert L.fv_jpeg_parse(ctypes.c_void_p(p), len(good), ctypes.byref(info)) == 0
+    out = np.zeros(int(info.total_coefs), np.int16)
+    assert L.fv_jpeg_entropy_decode(ctypes.c_void_p(p), len(good), ctypes.c_void_p(out.ctypes.data), out.size) == 0
+    assert np.array_equal(out, jpeg.entropy_decode(good, jpeg.parse(good)))
+
+
+def test_loader_falls_back_to_pillow_on_damaged_scan_data(tmp_path):
+    """a scan-level failure of the host Huffman decoder (bad code, run past the block) used to raise out of the
+    loader thread and abort train() / test(); libjpeg -- the reference's reader behind imread (fd.py:112, 798) -- only warns and
+    still returns an image.  The batch must go through Pillow instead."""
+    import pandas as pd
+    from face_vijnana_yolov3_amd import data, jpeg
+    from face_vijnana_yolov3_amd.face_detection import BatchFeeder
+    rng = np.random.default_rng(21)
+    good = _jpeg(rng, 96, 128, 2, 90)
+    sos = good.find(b'\xff\xda')
+    bad = None
+    for trial in range(400):                                        # a corruption the product refuses and Pillow still decodes
+        d = bytearray(good)
+        i = int(rng.integers(sos + 14, len(d) - 2))
+        d[i] = int(rng.integers(0, 255))
+        d = bytes(d)
+        info = jpeg.parse(d)
+        if info is None:
+            continue
+        try:
+            jpeg.entropy_decode(d, info)
+            continue
+        except ValueError:
+            pass
+        try:
+            Image.open(io.BytesIO(d)).convert('RGB')
+        except OSError:
+            continue
+        bad = d
+        break
+    assert bad is not None, 'no single-byte corruption found that the host decoder refuses and Pillow decodes'
+    root = str(tmp_path)
+    open(tmp_path / 'a.jpg', 'wb').write(good)
+    open(tmp_path / 'b.jpg', 'wb').write(bad)
+    rows = [[0, 'a.jpg', 1, 10.0, 12.0, 30.0, 30.0], [1, 'b.jpg', 1, 20.0, 22.0, 25.0, 35.0]]
+    pd.DataFrame(rows, columns=data.CSV_COLUMNS).to_csv(tmp_path / 'training.csv', index=False)
+    hps = dict(batch_size=2, step=1, lr=1e-4, beta_1=0.9, beta_2=0.99, decay=0.0)
+    seq = data.TrainingSequence(root, hps, {'image_size': 96, 'bb_info_c_size': 6})
+    f = BatchFeeder(seq, 1, 0, threads=2)
+    try:
+        packed, yt, weight, _ = f.load(0)
+    finally:
+        f.close()
+    assert not isinstance(packed[0], str), 'the damaged batch must not arrive as JPEG coefficients'
+    buf, offs, hw = packed
+    assert list(hw) == [96, 128, 96, 128] and tuple(yt.shape) == (2, 3, 3, 6)
+    want = np.asarray(Image.open(io.BytesIO(bad)).convert('RGB')).reshape(-1)
+    assert np.array_equal(buf.numpy()[offs[1]:offs[1] + want.size], want)
