@@ -64,3 +64,29 @@ def test_matches_loop_oracle(tmp_path, seed):
     assert len(res) == 10 and abs(res[0][0] - 0.5) < 1e-12 and abs(res[-1][0] - 0.95) < 1e-9
     assert all(res[i][1] >= res[i + 1][1] - 1e-12 for i in range(9))       # AP falls as the IoU bar rises
     assert abs(mean - np.mean([m for _, m in res])) < 1e-15
+
+
+def _golden_cases(tmp_path):
+    """tests/golden/cal_map_fd.npz: minted by RUNNING the reference's cal_mAP_fd (tests/golden/make_map_golden.py; the two
+    `.iat[:, k] = -1.0` lines that raise under every pandas are served by a shim for exactly that key shape)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cal_map_fd.npz'))
+    for ci in range(int(g['ncases'])):
+        gt = os.path.join(str(tmp_path), 'gt%d.csv' % ci); sol = os.path.join(str(tmp_path), 'sol%d.csv' % ci)
+        open(gt, 'wb').write(g['case%d_gt' % ci].tobytes()); open(sol, 'wb').write(g['case%d_sol' % ci].tobytes())
+        for th in g['thresholds']:
+            yield ci, float(th), gt, sol, g['case%d_th%g_ps' % (ci, th)], g['case%d_th%g_rs' % (ci, th)], float(g['case%d_th%g_map' % (ci, th)])
+
+
+def test_matches_the_reference_function_golden(tmp_path):
+    """PINNED (round 4): precision / recall after every detection equal the reference's bit for bit (ratios of the same
+    integers), mAP to 1e-12 (the same SciPy calls; the minting interpreter holds another SciPy release)."""
+    from face_vijnana_yolov3_amd.evaluate import cal_mAP_fd
+    from oracle import evaluate_oracle as eo
+    n = 0
+    for ci, th, gt, sol, ps_w, rs_w, map_w in _golden_cases(tmp_path):
+        for fn in (cal_mAP_fd, eo.cal_mAP_fd):
+            ps, rs, m = fn(gt, sol, th)
+            assert np.array_equal(np.asarray(ps), ps_w) and np.array_equal(np.asarray(rs), rs_w), (ci, th, fn.__module__)
+            assert abs(m - map_w) <= 1e-12, (ci, th, m, map_w)
+        n += 1
+    assert n == 20

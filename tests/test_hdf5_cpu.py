@@ -38,6 +38,28 @@ def test_reader_returns_what_libhdf5_wrote(golden_dir, tag):
         assert data['/chunked'].shape == (40, 6) and data['/chunked'].dtype == np.int32
 
 
+def test_reader_with_a_300_kb_model_config_attribute(golden_dir):
+    """A real face_detector.h5 carries ~300 KB of architecture JSON as the root attribute `model_config` (fd.py:630 model.save):
+    more than an object-header message holds, so libhdf5 stores the root's attributes densely (fractal heap + v2 B-tree).
+    Fixture written by libhdf5 (tests/golden/make_h5_bigattr_fixture.py): every dataset must come back bit for bit, the small
+    attributes too, and the big one either whole (checked by length and SHA-1) or not at all -- never garbled."""
+    import hashlib
+    want = {k.replace('|', '/'): v for k, v in np.load(os.path.join(golden_dir, 'keras_layout_bigattr.npz')).items()}
+    data, attrs = hdf5_lite.read_hdf5(os.path.join(golden_dir, 'keras_layout_bigattr.h5'))
+    ds = {k: v for k, v in want.items() if k.startswith('/')}
+    assert set(data) == set(ds) and len(ds) == 12
+    for k, v in data.items():
+        assert v.dtype == ds[k].dtype and v.shape == ds[k].shape and np.array_equal(v, ds[k]), k
+    assert [n.decode() for n in attrs['/model_weights']['layer_names']] == ['input1', 'model_1', 'output']
+    assert [n.decode() for n in attrs['/model_weights/output']['weight_names']] == ['output/kernel:0', 'output/bias:0']
+    cfg = attrs.get('/', {}).get('model_config')
+    if cfg is not None:
+        cfg = cfg if isinstance(cfg, bytes) else cfg.encode('utf8')
+        assert len(cfg) == int(want['model_config_len'])
+        assert np.array_equal(np.frombuffer(hashlib.sha1(cfg).digest(), np.uint8), want['model_config_sha1'])
+        assert json.loads(cfg)['config']['layers'][249]['name'] == 'conv_249'
+
+
 def _tiny_layers():
     layers, off, soff = [], 0, 0
     for idx, k, cin, cout in [(0, 3, 3, 4), (1, 3, 4, 8), (2, 1, 8, 4), (3, 3, 4, 8)]:

@@ -69,6 +69,7 @@ for mode in ('plain', 'rccl'):
             assert rel <= 1e-5, (cm, bb, rel)
             # a direct forward_backward with a callback on the same context afterwards is stream-ordered again (ADVICE r3)
             seen = []
+            eng.init_synthetic(seed=7)                  # the step above moved the weights
             eng.forward_backward(x, y, on_bucket=lambda off, cnt: seen.append((off, cnt)))
             torch.cuda.synchronize()
             assert seen and seen[0][0] + seen[0][1] == eng.n_params and seen[-1][0] == 0

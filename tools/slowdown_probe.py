@@ -117,6 +117,18 @@ def main():
             keep.append(e2)
         elif st == 'rehearsal':
             print(bench.rccl_world1_rehearsal(e1, x40, y40))
+        elif st == 'pinchurn':        # what the round-3 loaders did before PinnedRing: a fresh page-locked staging buffer per batch
+            import numpy as np
+            rng = np.random.default_rng(0)
+            held = []
+            for i in range(60):
+                t = torch.empty(int(rng.integers(35, 100)) << 20, dtype=torch.uint8).pin_memory()
+                t.cuda(non_blocking=True)
+                held.append(t)
+                if len(held) > 3:
+                    held.pop(0)
+            torch.cuda.synchronize()
+            keep.append(held)
         elif st == 'detect':
             print(bench.detect_bench(e1, x40))
         elif st == 'threescale':      # bench.three_scale_bench in this process (a second three-scale model + workspace)
