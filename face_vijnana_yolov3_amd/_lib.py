@@ -80,6 +80,7 @@ def _declare(L):
         'fv_state_count': (i64, []),
         'fv_workspace_bytes': (sz, [i32, i32, i32]),
         'fv_forward_infer': (i32, [vp, vp, vp, vp, i32, i32, vp, sz, vp]),
+        'fv_forward_base': (i32, [vp, vp, vp, vp, i32, i32, vp, sz, vp, vp]),
         'fv_train_step': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, sz, vp, vp, f64, BUCKET_FN, vp]),
         'fv_train_workspace_tensor': (i32, [i32, i32, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(i64)]),
         'fv_adam_step': (i32, [vp, vp, vp, vp, vp, i64, i64, f64, f64, f64, f64, f64]),

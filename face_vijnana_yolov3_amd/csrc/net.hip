@@ -224,10 +224,11 @@ int fv_train_workspace_tensor(int batch, int image_size, int layer, int which, s
     return FV_OK;
 }
 
-int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, const float* x, int batch, int image_size,
-                     void* workspace, size_t workspace_bytes, float* y) {
+// inference forward: the 52 base layers (the last one into `feat` when given), then the head into `y` when given
+static int forward_impl(fv_ctx* ctx, const float* params, const float* bn_state, const float* x, int batch, int image_size,
+                        void* workspace, size_t workspace_bytes, float* feat, float* y) {
     if (!ctx) return FV_ERR_INVALID;
-    FV_REQUIRE(ctx, params && bn_state && x && workspace && y, "forward_infer: NULL buffer");
+    FV_REQUIRE(ctx, params && bn_state && x && workspace && (y || feat), "forward_infer: NULL buffer");
     if (int rc = check_shape(ctx, batch, image_size)) return rc;
     Plan p = make_plan(workspace, batch, image_size, false);
     if (p.bytes > workspace_bytes) return fv_fail(ctx, FV_ERR_WORKSPACE, "forward_infer: workspace %zu < %zu bytes", workspace_bytes, p.bytes);
@@ -253,7 +254,7 @@ int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, co
         if (d.role == 1) { skip = cur; iskip = icur; }
         int iout = 0;
         while (iout == icur || (iout == iskip && (d.role == 1 || d.role == 2))) ++iout;
-        float* out = p.G[iout];
+        float* out = (feat && l == nb - 1) ? feat : p.G[iout];
         const float* w = l == 0 ? p.w0p : params + d.w_off;
         const long long rows = (long long)batch * (H / d.stride) * (H / d.stride);
         const int ks = l == 0 ? 1 : fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32);
@@ -271,6 +272,7 @@ int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, co
         cur = out; icur = iout;
         if (d.role == 2) { skip = nullptr; iskip = -1; }
     }
+    if (!y) return FV_OK;
     const auto& h = N.L[nb];
     const int G = image_size / h.in_div;
     const long long hrows = (long long)batch * G * G;
@@ -283,6 +285,18 @@ int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, co
     }
     return fv_op_conv_forward(ctx, cur, params + h.w_off, batch, G, G, h.cin, h.cout, 3, 1, FV_EPI_AFFINE, nullptr,
                               params + h.beta_off, 0.f, nullptr, y, nullptr, nullptr);
+}
+
+int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, const float* x, int batch, int image_size,
+                     void* workspace, size_t workspace_bytes, float* y) {
+    if (ctx && !y) return fv_fail(ctx, FV_ERR_INVALID, "forward_infer: NULL buffer");
+    return forward_impl(ctx, params, bn_state, x, batch, image_size, workspace, workspace_bytes, nullptr, y);
+}
+
+int fv_forward_base(fv_ctx* ctx, const float* params, const float* bn_state, const float* x, int batch, int image_size,
+                    void* workspace, size_t workspace_bytes, float* feat, float* y) {
+    if (ctx && !feat) return fv_fail(ctx, FV_ERR_INVALID, "forward_base: NULL buffer");
+    return forward_impl(ctx, params, bn_state, x, batch, image_size, workspace, workspace_bytes, feat, y);
 }
 
 int fv_train_step(fv_ctx* ctx, const float* params, float* bn_state, const float* x, const float* y_true, int batch,

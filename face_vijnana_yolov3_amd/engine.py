@@ -110,6 +110,20 @@ class Engine(object):
     def predict(self, x):
         return self.predict_device(x).cpu().numpy()
 
+    def predict_base_device(self, x, with_head=False):
+        """The base model alone (FaceDetector.YOLOV3Base, fd.py:384-600): x (B,S,S,3) -> the add_23 output (B,S/32,S/32,1024),
+        float32 CUDA tensor; with_head=True also returns the head output of the same pass."""
+        x = self._as_input(x)
+        B, S = x.shape[0], x.shape[1]
+        assert x.dim() == 4 and x.shape[2] == S and x.shape[3] == 3
+        ws = self._workspace(B, S, False)
+        feat = torch.empty((B, S // 32, S // 32, self.layers[-1]['cin']), dtype=torch.float32, device=self.dev)
+        y = torch.empty((B, S // 32, S // 32, HEAD_C), dtype=torch.float32, device=self.dev) if with_head else None
+        rc = lib().fv_forward_base(self.ctx.handle, ptr(self.params), ptr(self.state), ptr(x), B, S, ptr(ws), ws.numel(), ptr(feat),
+                                   ptr(y) if with_head else c_void_p(None))
+        self.ctx.check(rc, 'fv_forward_base')
+        return (feat, y) if with_head else feat
+
     # ------------------------------------------------------------------ training
     def ensure_optimizer(self):
         if self.grads is None:

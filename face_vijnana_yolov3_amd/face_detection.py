@@ -131,6 +131,22 @@ class FaceDetector(object):
             print('FaceDetector: neither %s nor %s found; using synthetic base weights'
                   % (self.BASE_MODEL_PATH, self.DARKNET_WEIGHTS_PATH))
 
+    @property
+    def YOLOV3Base(self):
+        """The Darknet-53 base as a model of its own (fd.py:384-600: "partial yolo3 model from the input layer to the add_23
+        layer"; the reference builds its detector around it, fd.py:344-352, and FaceIdentifier reuses it,
+        face_identification.py:323).  Here: a view of THIS detector's base weights with `predict` (numpy, as Keras),
+        `predict_device` (CUDA tensor) and `save` (the yolov3_base.h5 layout, fd.py:598) -- fv_forward_base underneath."""
+        if self.three_scale:
+            # the three-scale model keeps its base in the same flat layout at the same offsets: lend it to an Engine
+            from .engine import Engine
+            eng = Engine(self.model.ctx.device)
+            nb = eng.layers[-2]
+            n_p, n_s = nb['beta_off'] + nb['cout'], nb['var_off'] + nb['cout']
+            eng.params[:n_p].copy_(self.model.params[:n_p]); eng.state[:n_s].copy_(self.model.state[:n_s])
+            return YoloV3BaseModel(eng)
+        return YoloV3BaseModel(self.model)
+
     def _init_head(self, seed=None):
         """Keras default for the 'output' Conv2D: glorot_uniform kernel, zero bias (fd.py:348-352)."""
         import torch
@@ -373,6 +389,28 @@ class FaceDetector(object):
                     print(n + 1, '/', len(files), file_name)
                 self._write_rows(f, file_name, boxes)
         merge_rank_files(out_path, self.world, self.rank)
+
+
+class YoloV3BaseModel(object):
+    """What FaceDetector.YOLOV3Base hands out: input (B,S,S,3) in [0,1] -> (B,S/32,S/32,1024), the output of the last
+    residual add of the Darknet-53 base (fd.py:384-600).  A live view of the engine's weights, not a copy."""
+    trainable = True                                   # fd.py:396, 597
+
+    def __init__(self, engine):
+        self._eng = engine
+        self.output_channels = int(engine.layers[-1]['cin'])
+
+    def predict_device(self, x):
+        return self._eng.predict_base_device(x)
+
+    def predict(self, x):
+        return self.predict_device(x).cpu().numpy()
+
+    def save(self, path):
+        """base.save('yolov3_base.h5') (fd.py:598): one HDF5 group per Keras layer, no head."""
+        from . import weights
+        eng = self._eng
+        weights.write_keras_h5(path, eng.layers[:-1], eng.params.cpu().numpy(), eng.state.cpu().numpy(), nested=None)
 
 
 class BatchFeeder(object):

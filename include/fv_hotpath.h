@@ -160,6 +160,12 @@ size_t fv_workspace_bytes(int batch, int image_size, int training);
  * into the conv epilogue), x [batch][S][S][3] float32 NHWC in [0,1], y [batch][S/32][S/32][6]. */
 int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, const float* x, int batch,
                      int image_size, void* workspace, size_t workspace_bytes, float* y);
+/* The model `FaceDetector.YOLOV3Base` returns (fd.py:384-600): the Darknet-53 base alone, input -> the output of the last
+ * residual add (add_23), feat [batch][S/32][S/32][1024] float32 -- the tensor the head conv reads (fd.py:344-352) and the
+ * backbone output FaceIdentifier builds on (face_identification.py:323, 397-614).  Same kernels, same arithmetic and the same
+ * workspace as fv_forward_infer; y (may be NULL) additionally receives the head output of the same pass. */
+int fv_forward_base(fv_ctx* ctx, const float* params, const float* bn_state, const float* x, int batch,
+                    int image_size, void* workspace, size_t workspace_bytes, float* feat, float* y);
 
 /* Called (on the host, in enqueue order) when the gradient range [offset, offset+count) of the
  * flat gradient vector has been fully enqueued on the context's stream -- the hook a data-parallel

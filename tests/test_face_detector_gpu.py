@@ -243,3 +243,31 @@ def test_rows_do_not_depend_on_the_eval_batch_size_with_real_files(tmp_path, mon
         a = np.array([[float(v) for v in r[1:]] for r in rows[bs]]); b = np.array([[float(v) for v in r[1:]] for r in rows[1]])
         assert np.abs(a[:, :4] - b[:, :4]).max() <= 1e-6 * max(1.0, np.abs(b[:, :4]).max()), bs
         assert np.abs(a[:, 4] - b[:, 4]).max() <= 2e-6, bs
+
+
+@pytest.mark.parametrize('head', ['single', 'three_scale'])
+def test_yolov3_base_property(tmp_path, monkeypatch, head):
+    """FaceDetector.YOLOV3Base (fd.py:384-600; SURVEY 1, L3 API): the Darknet-53 base as a model of its own -- predict gives the
+    add_23 output the head reads; base.save writes the yolov3_base.h5 layout (fd.py:598), which a detector configured with
+    yolov3_base_model_load then loads (fd.py:393-396)."""
+    import torch
+    from face_vijnana_yolov3_amd.face_detection import FaceDetector
+    from face_vijnana_yolov3_amd.engine import Engine
+    monkeypatch.chdir(tmp_path)
+    conf = _conf(str(tmp_path), 'test', image_size=96)
+    conf['nn_arch']['head'] = head
+    fd = FaceDetector(conf)
+    base = fd.YOLOV3Base
+    assert base.trainable is True
+    x = np.random.default_rng(1).uniform(0, 1, (2, 96, 96, 3)).astype(np.float32)
+    f = base.predict(x)
+    assert f.shape == (2, 3, 3, 1024) and f.dtype == np.float32 and np.isfinite(f).all() and f.std() > 0
+    if head == 'single':
+        # the head conv applied to these features is the detector's own output
+        feat, y = fd.model.predict_base_device(torch.from_numpy(x), with_head=True)
+        assert np.array_equal(feat.cpu().numpy(), f) and np.array_equal(y.cpu().numpy(), fd.model.predict(x))
+    base.save('yolov3_base.h5')
+    conf2 = _conf(str(tmp_path), 'test', image_size=96)
+    conf2['yolov3_base_model_load'] = True
+    fd2 = FaceDetector(conf2)
+    assert np.array_equal(fd2.YOLOV3Base.predict(x), f)

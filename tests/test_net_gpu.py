@@ -91,6 +91,26 @@ def test_forward_infer_matches_oracle(eng, B, S):
     _within(y.cpu(), y64, y32, 'forward_infer')
 
 
+@pytest.mark.parametrize('B,S', [(1, 96), (2, 128), (16, 64)])
+def test_forward_base_matches_oracle_and_the_head_pass(eng, B, S):
+    """fv_forward_base = FaceDetector.YOLOV3Base (fd.py:384-600): the add_23 output (B, S/32, S/32, 1024) against the oracle's
+    last base activation; the head output of the same pass is bit-identical to fv_forward_infer's, and so is the feature
+    tensor whether or not the head is asked for."""
+    from oracle import net_oracle as no
+    p64, s64, x, _ = _setup(6, B, S)
+    _, _, inter64 = no.forward(p64, s64, x, training=False, return_intermediates=True)
+    _, _, inter32 = no.forward(p64.float(), s64.float(), x.float(), training=False, return_intermediates=True)
+    last = [e['name'] for e in no.param_layout()[0] if e['has_bn']][-1]
+    eng.set_params(p64.float(), s64.float())
+    feat = eng.predict_base_device(x.float())
+    feat2, y2 = eng.predict_base_device(x.float(), with_head=True)
+    y = eng.predict_device(x.float())
+    torch.cuda.synchronize()
+    assert tuple(feat.shape) == (B, S // 32, S // 32, 1024)
+    _within(feat.cpu(), inter64[last][1], inter32[last][1], 'forward_base')
+    assert torch.equal(feat, feat2) and torch.equal(y, y2)
+
+
 def test_train_step_matches_oracle(eng):
     from oracle import net_oracle as no
     B, S = 4, 96

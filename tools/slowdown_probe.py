@@ -129,6 +129,9 @@ def main():
                     held.pop(0)
             torch.cuda.synchronize()
             keep.append(held)
+        elif st == 'loader':          # bench.loader_bench in this process (BatchFeeder: 16 host threads, pinned ring, staging stream)
+            from face_vijnana_yolov3_amd.parallel import DataParallelTrainer
+            print(bench.loader_bench(e1, DataParallelTrainer(e1, world_size=1, rank=0), 40, 416, 8))
         elif st == 'detect':
             print(bench.detect_bench(e1, x40))
         elif st == 'threescale':      # bench.three_scale_bench in this process (a second three-scale model + workspace)
