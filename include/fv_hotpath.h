@@ -89,6 +89,17 @@ int fv_set_bn_zero_debias_step(fv_ctx* ctx, long long step);
 /* First layer (3 -> 32 channels, K = 27, HBM-bound): 1 (default) a direct vector-FMA kernel with an LDS halo tile
  * whenever W % 32 == 0 and H % 8 == 0; 0 the matrix-core gather kernel.  Bit-identical outputs (same fmaf chain). */
 int fv_set_conv0_direct(fv_ctx* ctx, int on);
+/* Small-M inference (batch 1 at 416 x 416: what `self.model.predict(image)` of detect() is, fd.py:899): layers 9 .. 51 and the head of
+ * fv_forward_infer run as ONE cooperative launch of persistent workgroups with bounded device-side layer barriers instead of ~75
+ * dependent launches.  mode 0: off (per-layer launches); 1 (default): on; 2: on with the per-layer path's K-split plan -- bit-identical
+ * to mode 0.  grid: workgroups of the launch (multiple of 8; 0 = two per CU, checked by the runtime against the occupancy).  A
+ * launch the runtime refuses falls back to mode 0; a wait abandoned on the device is reported by the next fv_forward_infer /
+ * fv_infer_persist_status (synchronises) as FV_ERR_HIP. */
+int fv_set_infer_persist(fv_ctx* ctx, int mode, int grid);
+int fv_infer_persist_status(fv_ctx* ctx);
+/* Per-phase wall-clock stamps of workgroup 0 of the next one-launch forwards (on != 0); with us != NULL first returns those of the last
+ * launch: for every phase its start, the end of its tile loop, the end of its slab reduction, then the end of the launch; microseconds. */
+int fv_infer_persist_trace(fv_ctx* ctx, int on, double* us, int max_stamps, int* n_out);
 /* The per-operator conv entry points (fv_conv2d_forward / fv_conv2d_dgrad) have no workspace
  * argument; a caller that wants the tail split there lends device scratch here (NULL, 0 = none;
  * 64 MiB covers every Darknet-53 shape at batch 40).  The buffer must stay valid until the calls that

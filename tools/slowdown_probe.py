@@ -92,7 +92,22 @@ def main():
                         print('    %-34s %8.3f -> %8.3f   x%.3f' % (k, ta[k], tb[k], tb[k] / ta[k]))
             print('    %-34s %8.3f -> %8.3f   x%.3f' % ('sum', tot_a, tot_b, tot_b / tot_a), flush=True)
 
+    def late_models(label):
+        """Models whose CONTEXTS (side stream, events) are created now: is it the creation order that decides?"""
+        m2 = Yolov3(0, out_channels=255); m2.init_synthetic(3)
+        e3 = Engine(0); e3.init_synthetic(7)
+        three = timed(lambda: m2.train_on_batch(x16, tg, 1e-4, 0.9, 0.99), 5)
+        base = timed(lambda: e3.train_on_batch(x40, y40, **bench.HPS), 5)
+        e3.ctx.set_overlap(False); m2.ctx.set_overlap(False)
+        three_s = timed(lambda: m2.train_on_batch(x16, tg, 1e-4, 0.9, 0.99), 3)
+        base_s = timed(lambda: e3.train_on_batch(x40, y40, **bench.HPS), 3)
+        print('%-46s NEW contexts: three-scale %.2f ms  base %.2f ms   (weight-gradients on the compute stream: %.2f / %.2f)' % (
+            label, three, base, three_s, base_s), flush=True)
+        del m2, e3
+        torch.cuda.empty_cache()
+
     measure('fresh')
+    late_models('fresh')
     stages = args.stages.split(',')
     keep = []
     for st in stages:
@@ -138,10 +153,12 @@ def main():
             print(bench.three_scale_bench(0, 416, steps=3))
         if args.each:
             measure('after ' + st)
+            late_models('after ' + st)
     if not args.each:
         measure('after ' + '+'.join(stages))
     last = list(tables)[-1]
     compare('fresh', last)
+    late_models(last)
     # ---- back to the fast state?
     del keep[:]
     import gc; gc.collect()
