@@ -101,6 +101,12 @@ int fv_set_conv0_direct(fv_ctx* ctx, int on) {
     return FV_OK;
 }
 
+int fv_set_fuse_finish1x1(fv_ctx* ctx, int on) {
+    if (!ctx) return FV_ERR_INVALID;
+    ctx->fuse_finish1x1 = on != 0;
+    return FV_OK;
+}
+
 int fv_set_infer_persist(fv_ctx* ctx, int mode, int grid) {
     if (!ctx || mode < 0 || mode > 2 || grid < 0 || (grid % 8) != 0) return FV_ERR_INVALID;
     ctx->infer_persist = mode;
@@ -165,6 +171,7 @@ int fv_create(int device, void* stream, fv_ctx** out) {
     fv_ctx* c = new fv_ctx();
     c->device = device;
     if (const char* e = getenv("FV_CONV_WAVES8")) c->conv_waves8 = e[0] != '0';
+    if (const char* e = getenv("FV_FUSE_FINISH1X1")) c->fuse_finish1x1 = e[0] != '0';
     if (const char* e = getenv("FV_INFER_PERSIST")) c->infer_persist = e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
     c->stream = (hipStream_t)stream;
     // The side stream carries the weight-gradient kernels of the backward overlap at the LOWEST stream priority:

@@ -38,7 +38,8 @@ struct fv_ctx {
     bool conv0_direct = true;    // fv_set_conv0_direct: vector-FMA first layer (conv0_direct.hip) instead of the gather kernel
     // one-launch small-M inference forward (infer_persist.hip; fv_set_infer_persist): 0 off, 1 on, 2 on with the per-layer path's
     // K-split plan (bit-identical to it)
-    int infer_persist = 1;
+    bool fuse_finish1x1 = false;          // fv_set_fuse_finish1x1: per-layer small-M path: split-K finish + following 1x1 layer in one launch (measured at parity: off)
+    int infer_persist = 0;                // (measured at parity with the per-layer launches, DESIGN 10: opt-in)
     int persist_grid = 0;                 // workgroups of the cooperative launch; 0: two per CU, checked against the occupancy query
     void* persist_table = nullptr;        // device copy of the phase table (ctx-owned: nothing else may write it) and what it was built for
     int persist_key[4] = {0, 0, 0, 0};    // batch, image_size, grid, mode

@@ -310,7 +310,9 @@ static int persist_forward(fv_ctx* ctx, const Plan& p, const float* params, floa
     if (grid == 0) {
         int per_cu = 0, cus = 0;
         if (int rc = fv_persist_max_grid(ctx, &per_cu, &cus)) return rc;
-        grid = (per_cu < 2 ? per_cu : 2) * cus;
+        // one workgroup per CU: measured 1.03 ms in-kernel against 1.11 with two per CU (the second workgroup buys a faster K step,
+        // 1.9 against 2.25 us, and pays for it with twice the arrivals and pollers at every wait and a finer K split)
+        grid = per_cu >= 1 ? cus : 0;
         if (grid > PERSIST_MAX_GRID) grid = PERSIST_MAX_GRID;
         grid &= ~7;
     }
@@ -421,6 +423,23 @@ static int forward_impl(fv_ctx* ctx, const float* params, const float* bn_state,
             // small M (batch-1 latency): K-split partial slabs, summed in fixed order by the finish kernel
             if (int rc = fv_op_conv_forward(ctx, cur, w, batch, H, H, d.cin, d.cout, d.ksize, d.stride, 0, nullptr, nullptr, 0.f,
                                             nullptr, p.slab, nullptr, nullptr, ks)) return rc;
+            // ... fused with the 1x1 layer of the next residual block where that is a narrow unsplit launch today (52x52 and 26x26 at
+            // batch 1): one launch instead of finish + conv, bit-identical (finish_conv1x1.hip)
+            const bool fuse = ctx->fuse_finish1x1 && l + 1 < nb && N.L[l + 1].ksize == 1 && N.L[l + 1].role == 1 &&
+                              fv_ew_finish_conv1x1_ok(d.cout, N.L[l + 1].cout, rows) &&
+                              fv_conv_choose_ksplit((int)rows, N.L[l + 1].cout, N.L[l + 1].cin / 32) == 1 && !(feat && l + 1 == nb - 1);
+            if (fuse) {
+                const auto& d1 = N.L[l + 1];
+                int iout1 = 0;
+                while (iout1 == iout) ++iout1;             // layer l+1 opens a block: its input (= out) is the block's skip tensor
+                if (int rc = fv_ew_finish_conv1x1(ctx, p.slab, ks, rows * d.cout, p.scale[l], p.shift[l], d.role == 2 ? skip : nullptr, out,
+                                                  params + d1.w_off, p.scale[l + 1], p.shift[l + 1], p.G[iout1], (int)rows, d.cout, d1.cout,
+                                                  LEAKY)) return rc;
+                skip = out; iskip = iout;
+                cur = p.G[iout1]; icur = iout1;
+                ++l;
+                continue;
+            }
             if (int rc = fv_ew_splitk_finish(ctx, p.slab, ks, rows * d.cout, p.scale[l], p.shift[l], d.role == 2 ? skip : nullptr,
                                              out, rows * d.cout, d.cout, LEAKY, 1)) return rc;
         } else {

@@ -23,8 +23,14 @@ def main():
         return e0.elapsed_time(e1) / n
 
     eng.ctx.set_infer_persist(0)
+    eng.ctx.set_fuse_finish1x1(False)
     y0 = eng.predict_device(x).clone(); torch.cuda.synchronize()
     print('per-layer path        %.4f ms/img' % timed(), flush=True)
+    eng.ctx.set_fuse_finish1x1(True)
+    yf = eng.predict_device(x).clone(); torch.cuda.synchronize()
+    print('per-layer path, finish + 1x1 fused: bit-identical %s   %.4f ms/img' % (torch.equal(yf, y0), timed()), flush=True)
+    if len(sys.argv) > 3:
+        return
     for grid in grids:
         for mode in (2, 1):
             eng.ctx.set_infer_persist(mode, grid)
