@@ -118,6 +118,8 @@ def _declare(L):
         'fv_yolov3_train_workspace_bytes': (sz, [i32, i32, i32]),
         'fv_yolov3_train_step': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, vp, f64, BUCKET_FN, vp]),
         'fv_yolov3_train_workspace_tensor': (i32, [i32, i32, i32, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(i64)]),
+        'fv_yolo_decode_nms_batch': (i32, [vp, vp, vp, vp, i32, i32, i32, ctypes.POINTER(f32), f32, f64, i32, i32, i32, i32, i32,
+                                           vp, vp, vp, vp]),
         'fv_yolo_decode_nms': (i32, [vp, vp, vp, vp, i32, i32, ctypes.POINTER(f32), f32, f64, i32, i32, i32, i32, i32,
                                      vp, vp, vp, vp]),
     }
@@ -215,17 +217,18 @@ class Context:
             self.check(lib().fv_set_conv_scratch(self._h, c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size()),
                        'fv_set_conv_scratch')
 
-    def profile(self, on):
-        self.check(lib().fv_profile_enable(self._h, 1 if on else 0), 'fv_profile_enable')
+    def profile(self, on, shapes=False):
+        """on: HIP-event pairs around every launch; shapes=True: the matrix kernels' records carry their problem shape in the name."""
+        self.check(lib().fv_profile_enable(self._h, (2 if shapes else 1) if on else 0), 'fv_profile_enable')
 
     def profile_collect(self):
         """-> {kernel name: dict(launches, ms, flops, bytes)} since profiling was enabled (syncs)."""
-        recs = (ProfileRec * 64)()
+        recs = (ProfileRec * 512)()
         n = ctypes.c_int(0)
-        self.check(lib().fv_profile_collect(self._h, recs, 64, ctypes.byref(n)), 'fv_profile_collect')
+        self.check(lib().fv_profile_collect(self._h, recs, 512, ctypes.byref(n)), 'fv_profile_collect')
         return {recs[i].name.decode(): dict(launches=int(recs[i].launches), ms=recs[i].ms_total,
                                             flops=recs[i].flops_total, bytes=recs[i].bytes_total)
-                for i in range(min(n.value, 64))}
+                for i in range(min(n.value, 512))}
 
     def close(self):
         if self._h:

@@ -18,6 +18,7 @@ int fv_fail(fv_ctx* ctx, int code, const char* fmt, ...) {
 fv_ctx::~fv_ctx() {
     for (auto& r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : ev_pool) (void)hipEventDestroy(e);
+    for (auto* n : prof_names) delete n;
     for (int i = 0; i < 2; ++i) {
         if (ev_dz[i]) (void)hipEventDestroy(ev_dz[i]);
         if (ev_wg[i]) (void)hipEventDestroy(ev_wg[i]);
@@ -35,13 +36,24 @@ static hipEvent_t take_event(fv_ctx* c) {
     return e;
 }
 
-FvProfScope::FvProfScope(fv_ctx* c, const char* name, double flops, double bytes) : ctx(c) {
+void FvProfScope::begin(fv_ctx* c, const char* name, double flops, double bytes) {
     if (!c || !c->prof_on) return;
     hipEvent_t e0 = take_event(c);
     e1 = take_event(c);
     if (!e0 || !e1) { e1 = nullptr; return; }
     (void)hipEventRecord(e0, c->stream);
     c->prof.push_back(FvProfRec{name, flops, bytes, e0, e1});
+}
+FvProfScope::FvProfScope(fv_ctx* c, const char* name, double flops, double bytes) : ctx(c) { begin(c, name, flops, bytes); }
+FvProfScope::FvProfScope(fv_ctx* c, const char* name, const std::string& tag, double flops, double bytes) : ctx(c) {
+    if (c && c->prof_on && c->prof_shapes) {
+        const std::string full = std::string(name) + " " + tag;
+        for (auto* s : c->prof_names) if (*s == full) { begin(c, s->c_str(), flops, bytes); return; }
+        c->prof_names.push_back(new std::string(full));
+        begin(c, c->prof_names.back()->c_str(), flops, bytes);
+        return;
+    }
+    begin(c, name, flops, bytes);
 }
 FvProfScope::~FvProfScope() {
     if (e1) (void)hipEventRecord(e1, ctx->stream);
@@ -124,6 +136,7 @@ int fv_set_conv_scratch(fv_ctx* ctx, void* buf, size_t bytes) {
 int fv_profile_enable(fv_ctx* ctx, int on) {
     if (!ctx) return FV_ERR_INVALID;
     ctx->prof_on = on != 0;
+    ctx->prof_shapes = on == 2;
     return FV_OK;
 }
 

@@ -18,6 +18,8 @@ struct fv_ctx {
     std::string err;
     // optional per-launch timing (fv_profile_enable): HIP event pairs on the launch stream
     bool prof_on = false;
+    bool prof_shapes = false;          // fv_profile_enable(ctx, 2): the matrix kernels' records carry their problem shape in the name
+    std::vector<std::string*> prof_names;   // interned shape-tagged names (stable addresses for FvProfRec::name)
     std::vector<FvProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
     // backward-pass overlap: weight-gradient kernels run on a side stream next to the
@@ -56,6 +58,9 @@ struct FvProfScope {
     fv_ctx* ctx;
     hipEvent_t e1 = nullptr;
     FvProfScope(fv_ctx* c, const char* name, double flops, double bytes);
+    // shape-tagged form: `tag` is appended to the name when fv_profile_enable(ctx, 2) is active
+    FvProfScope(fv_ctx* c, const char* name, const std::string& tag, double flops, double bytes);
+    void begin(fv_ctx* c, const char* name, double flops, double bytes);
     ~FvProfScope();
 };
 

@@ -571,7 +571,9 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
     static const std::string name_s = "conv_kernel<" + std::to_string(BN) + "," + std::to_string(WM_) + "," + std::to_string(WN_) +
                                       (G ? ",true>" : ",false>");   // rocprofv3's name up to the first four template arguments
     static const char* name = name_s.c_str();
-    FvProfScope ps(ctx, name, a.alg_flops,
+    FvProfScope ps(ctx, name, "M" + std::to_string(a.M) + " N" + std::to_string(a.Nout) + " K" + std::to_string(a.taps[0].n * a.Cin) +
+                                  (a.nclass > 1 ? " s2" : "") + (a.ksplit > 1 ? " ks" + std::to_string(a.ksplit) : "") + ((a.epi & FV_EPI_BNRED) ? " r" : ""),
+                   a.alg_flops,
                    4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.Nout * a.Tw * a.Cin +
                           (double)a.M * a.nclass * a.Nout * ((a.epi & FV_EPI_ADD) ? 2 : 1)));
     FvConvArgs b = a;

@@ -27,6 +27,7 @@ struct YoloDecodeArgs {
     float x_off, x_sc, y_off, y_sc;   // correct_yolo_boxes constants (float32-rounded python floats)
     int capacity;
     int* boxes; float* objness; float* classes; int* count;
+    long long ystride[3];             // floats between the images of a batch (blockIdx.x = image)
 };
 
 __global__ __launch_bounds__(1024) void yolo_decode_kernel(const YoloDecodeArgs a) {
@@ -36,6 +37,10 @@ __global__ __launch_bounds__(1024) void yolo_decode_kernel(const YoloDecodeArgs 
     if (tid == 0) base = 0;
     __syncthreads();
     const int C = 5 + a.nclass;
+    const int img = blockIdx.x;
+    int* const boxes = a.boxes + (size_t)img * a.capacity * 4;
+    float* const objness = a.objness + (size_t)img * a.capacity;
+    float* const classes = a.classes + (size_t)img * a.capacity * a.nclass;
     for (int s = 0; s < 3; ++s) {
         const int g = a.grid0 << s;
         const int nkeep = s == 1 ? 2 : 1;               // skip list: keep b=1 | b=0,2 | b=1
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(1024) void yolo_decode_kernel(const YoloDecodeArgs 
             if (slot < nslots) {
                 cell = slot / nkeep;
                 b = s == 1 ? (slot - cell * nkeep) * 2 : 1;
-                t = a.y[s] + ((size_t)cell * 3 + b) * C;
+                t = a.y[s] + (size_t)img * a.ystride[s] + ((size_t)cell * 3 + b) * C;
                 conf = sigf(t[4]);
                 keep = !(conf < a.obj_thresh);
             }
@@ -71,16 +76,16 @@ __global__ __launch_bounds__(1024) void yolo_decode_kernel(const YoloDecodeArgs 
                 bx.z = (int)((xmax - a.x_off) / a.x_sc * (float)a.image_w);
                 bx.y = (int)((ymin - a.y_off) / a.y_sc * (float)a.image_h);
                 bx.w = (int)((ymax - a.y_off) / a.y_sc * (float)a.image_h);
-                reinterpret_cast<int4*>(a.boxes)[pos] = bx;
-                a.objness[pos] = conf;
-                for (int c = 0; c < a.nclass; ++c) a.classes[(size_t)pos * a.nclass + c] = sigf(t[5 + c]);
+                reinterpret_cast<int4*>(boxes)[pos] = bx;
+                objness[pos] = conf;
+                for (int c = 0; c < a.nclass; ++c) classes[(size_t)pos * a.nclass + c] = sigf(t[5 + c]);
             }
             __syncthreads();
             if (tid == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += wave_cnt[w]; base += tot; }
             __syncthreads();
         }
     }
-    if (tid == 0) *a.count = base < a.capacity ? base : a.capacity;
+    if (tid == 0) a.count[img] = base < a.capacity ? base : a.capacity;
 }
 
 __device__ __forceinline__ int ovl(int x1, int x2, int x3, int x4) {
@@ -90,8 +95,11 @@ __device__ __forceinline__ int ovl(int x1, int x2, int x3, int x4) {
 }
 
 template <int P>
-__global__ __launch_bounds__(1024) void yolo_nms_kernel(const int* __restrict__ boxes, float* __restrict__ classes,
-                                                        const int* __restrict__ count, int nclass, double nms_thresh) {
+__global__ __launch_bounds__(1024) void yolo_nms_kernel(const int* __restrict__ boxes_all, float* __restrict__ classes_all,
+                                                        const int* __restrict__ count_all, int nclass, double nms_thresh, int capacity) {
+    const int* __restrict__ boxes = boxes_all + (size_t)blockIdx.y * capacity * 4;          // blockIdx.y = image of the batch
+    float* __restrict__ classes = classes_all + (size_t)blockIdx.y * capacity * nclass;
+    const int* __restrict__ count = count_all + blockIdx.y;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);      // [P]
     float* pv = reinterpret_cast<float*>(smem + (size_t)P * 8);                  // [P] current class prob by candidate
@@ -139,17 +147,19 @@ __global__ __launch_bounds__(1024) void yolo_nms_kernel(const int* __restrict__ 
 
 }  // namespace
 
-extern "C" int fv_yolo_decode_nms(fv_ctx* ctx, const float* y13, const float* y26, const float* y52, int grid0, int nclass,
-                                  const float* anchors18, float obj_thresh, double nms_thresh, int net_h, int net_w, int image_h,
-                                  int image_w, int capacity, int32_t* boxes, float* objness, float* classes, int32_t* count) {
+extern "C" int fv_yolo_decode_nms_batch(fv_ctx* ctx, const float* y13, const float* y26, const float* y52, int nimg, int grid0, int nclass,
+                                        const float* anchors18, float obj_thresh, double nms_thresh, int net_h, int net_w, int image_h,
+                                        int image_w, int capacity, int32_t* boxes, float* objness, float* classes, int32_t* count) {
     if (!ctx) return FV_ERR_INVALID;
     FV_REQUIRE(ctx, y13 && y26 && y52 && anchors18 && boxes && objness && classes && count, "yolo_decode_nms: NULL buffer");
-    FV_REQUIRE(ctx, grid0 >= 1 && nclass >= 1 && capacity >= 1 && capacity <= 8192, "yolo_decode_nms: capacity must be 1..8192");
+    FV_REQUIRE(ctx, nimg >= 1 && nimg <= 65535 && grid0 >= 1 && nclass >= 1 && capacity >= 1 && capacity <= 8192,
+               "yolo_decode_nms: capacity must be 1..8192, images 1..65535");
     FV_REQUIRE(ctx, ((uintptr_t)boxes & 15) == 0, "yolo_decode_nms: boxes must be 16-byte aligned");
     YoloDecodeArgs a{};
     a.y[0] = y13; a.y[1] = y26; a.y[2] = y52;
     a.grid0 = grid0; a.nclass = nclass; a.obj_thresh = obj_thresh;
     for (int i = 0; i < 18; ++i) a.anchors[i] = anchors18[i];
+    for (int s = 0; s < 3; ++s) a.ystride[s] = (long long)(grid0 << s) * (grid0 << s) * 3 * (5 + nclass);
     a.net_h = net_h; a.net_w = net_w; a.image_h = image_h; a.image_w = image_w;
     // correct_yolo_boxes (yd.py:389-399), including the reference's `new_h = net_w` in the else branch
     double new_w, new_h;
@@ -158,18 +168,26 @@ extern "C" int fv_yolo_decode_nms(fv_ctx* ctx, const float* y13, const float* y2
     a.x_off = (float)((net_w - new_w) / 2. / net_w); a.x_sc = (float)(new_w / net_w);
     a.y_off = (float)((net_h - new_h) / 2. / net_h); a.y_sc = (float)(new_h / net_h);
     a.capacity = capacity; a.boxes = boxes; a.objness = objness; a.classes = classes; a.count = count;
-    hipLaunchKernelGGL(yolo_decode_kernel, dim3(1), dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3(nimg), dim3(1024), 0, ctx->stream, a);
     FV_LAUNCH_CHECK(ctx);
     int P = 1024;
     while (P < capacity) P <<= 1;
     const size_t lds = (size_t)P * 12;
-    if (P == 1024) hipLaunchKernelGGL(yolo_nms_kernel<1024>, dim3(nclass), dim3(1024), lds, ctx->stream, boxes, classes, count, nclass, nms_thresh);
-    else if (P == 2048) hipLaunchKernelGGL(yolo_nms_kernel<2048>, dim3(nclass), dim3(1024), lds, ctx->stream, boxes, classes, count, nclass, nms_thresh);
-    else if (P == 4096) hipLaunchKernelGGL(yolo_nms_kernel<4096>, dim3(nclass), dim3(1024), lds, ctx->stream, boxes, classes, count, nclass, nms_thresh);
+    const dim3 grid(nclass, nimg);
+    if (P == 1024) hipLaunchKernelGGL(yolo_nms_kernel<1024>, grid, dim3(1024), lds, ctx->stream, boxes, classes, count, nclass, nms_thresh, capacity);
+    else if (P == 2048) hipLaunchKernelGGL(yolo_nms_kernel<2048>, grid, dim3(1024), lds, ctx->stream, boxes, classes, count, nclass, nms_thresh, capacity);
+    else if (P == 4096) hipLaunchKernelGGL(yolo_nms_kernel<4096>, grid, dim3(1024), lds, ctx->stream, boxes, classes, count, nclass, nms_thresh, capacity);
     else {
         FV_HIP(ctx, hipFuncSetAttribute((const void*)yolo_nms_kernel<8192>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(yolo_nms_kernel<8192>, dim3(nclass), dim3(1024), lds, ctx->stream, boxes, classes, count, nclass, nms_thresh);
+        hipLaunchKernelGGL(yolo_nms_kernel<8192>, grid, dim3(1024), lds, ctx->stream, boxes, classes, count, nclass, nms_thresh, capacity);
     }
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
+}
+
+extern "C" int fv_yolo_decode_nms(fv_ctx* ctx, const float* y13, const float* y26, const float* y52, int grid0, int nclass,
+                                  const float* anchors18, float obj_thresh, double nms_thresh, int net_h, int net_w, int image_h,
+                                  int image_w, int capacity, int32_t* boxes, float* objness, float* classes, int32_t* count) {
+    return fv_yolo_decode_nms_batch(ctx, y13, y26, y52, 1, grid0, nclass, anchors18, obj_thresh, nms_thresh, net_h, net_w, image_h, image_w,
+                                    capacity, boxes, objness, classes, count);
 }

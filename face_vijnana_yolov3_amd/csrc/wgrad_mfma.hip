@@ -336,8 +336,8 @@ int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
                               : GATHER ? (TM == 64 ? "wgrad_kernel<64,32,gather>" : "wgrad_kernel<32,32,gather>")
                               : TM == 64 ? (TN == 64 ? "wgrad_kernel<64,64>" : "wgrad_kernel<64,32>")
                                          : (TN == 64 ? "wgrad_kernel<32,64>" : "wgrad_kernel<32,32>");
-    FvProfScope ps(ctx, name, a.alg_flops,
-                   4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.M * a.N + (double)a.N * a.Tw * a.Cin));
+    FvProfScope ps(ctx, name, "M" + std::to_string(a.M) + " N" + std::to_string(a.N) + " C" + std::to_string(a.Cin) + " t" + std::to_string(a.taps.n),
+                   a.alg_flops, 4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.M * a.N + (double)a.N * a.Tw * a.Cin));
     const int nsplit8 = pinned ? (nsplit + 7) / 8 * 8 : nsplit;   // padded splits return at once (no chunks)
     if constexpr (QUAD) {
         if (ctx->conv_waves8)

@@ -206,7 +206,18 @@ class FaceDetector(object):
         import torch
         x = images if torch.is_tensor(images) else np.asarray(images, dtype=np.float32)
         if self.three_scale:
-            return ('three_scale', x)
+            # the reference's decode_netout -> correct_yolo_boxes -> do_nms chain (yolov3_detect.py:335-444; its driver loops over the
+            # images, yd.py:596-604) on the letterboxed images: ONE launch pair for the batch (fv_yolo_decode_nms_batch), results
+            # into pinned memory behind an event, like the single-scale head
+            from .yolov3 import decode_nms_batch
+            S = self.image_size
+            ys = self.model.predict_device(x)
+            res = decode_nms_batch(self.model.ctx, ys[0], ys[1], ys[2], (S, S), (S, S), obj_thresh=self.hps['face_conf_th'],
+                                   nms_thresh=self.hps['nms_iou_th'])
+            host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True).copy_(v, non_blocking=True) for k, v in res.items()}
+            ev = torch.cuda.Event()
+            ev.record()
+            return ('three_scale', host, ev, int(ys[0].shape[0]))
         y = self.model.predict_device(x)
         res = decode_nms(self.model.ctx, y, self.image_size, self.hps['face_conf_th'], self.hps['nms_iou_th'],
                          self.hps['num_cands'])
@@ -217,30 +228,22 @@ class FaceDetector(object):
         return ('single', host, ev, int(y.shape[0]))
 
     def _detect_collect(self, launched):
-        if launched[0] == 'three_scale':
-            return self._detect_three_scale(launched[1])
-        _tag, host, ev, n = launched
+        tag, host, ev, n = launched
         ev.synchronize()
+        if tag == 'three_scale':
+            return [self._three_scale_boxes(host, b) for b in range(n)]
         return [to_boundboxes(host, b) for b in range(n)]
 
-    def _detect_three_scale(self, x):
-        """Three-scale head: the reference's decode_netout -> correct_yolo_boxes -> do_nms chain (yolov3_detect.py:335-444,
-        one fv_yolo_decode_nms launch pair per image) on the letterboxed image, so boxes come back in network pixels like the
-        single-scale detect(); then detect()'s own tail (fd.py:942-947): score > 0, ascending, at most num_cands."""
-        from .yolov3 import decode_nms as yolo_decode_nms
-        S = self.image_size
-        ys = self.model.predict_device(x)
-        out = []
-        for b in range(ys[0].shape[0]):
-            r = yolo_decode_nms(self.model.ctx, ys[0][b], ys[1][b], ys[2][b], (S, S), (S, S), obj_thresh=self.hps['face_conf_th'],
-                                nms_thresh=self.hps['nms_iou_th'])
-            bx = r['boxes'].cpu().numpy().astype(np.int64); ob = r['objness'].cpu().numpy(); cl = r['classes'].cpu().numpy()
-            boxes = [BoundBox(bx[k, 0], bx[k, 1], bx[k, 2], bx[k, 3], objness=ob[k], classes=list(cl[k])) for k in range(bx.shape[0])]
-            boxes = [bb for bb in boxes if bb.get_score() > 0]
-            scores = np.array([bb.get_score() for bb in boxes], np.float32)
-            order = np.argsort(scores, kind='stable')
-            out.append([boxes[i] for i in order[:self.hps['num_cands']]])
-        return out
+    def _three_scale_boxes(self, host, b):
+        """Image b of a decoded batch -> detect()'s own tail (fd.py:942-947): boxes in network pixels, score > 0, ascending score, at
+        most num_cands."""
+        n = int(host['count'][b])
+        bx = host['boxes'][b, :n].numpy().astype(np.int64); ob = host['objness'][b, :n].numpy(); cl = host['classes'][b, :n].numpy()
+        boxes = [BoundBox(bx[k, 0], bx[k, 1], bx[k, 2], bx[k, 3], objness=ob[k], classes=list(cl[k])) for k in range(n)]
+        boxes = [bb for bb in boxes if bb.get_score() > 0]
+        scores = np.array([bb.get_score() for bb in boxes], np.float32)
+        order = np.argsort(scores, kind='stable')
+        return [boxes[i] for i in order[:self.hps['num_cands']]]
 
     # ------------------------------------------------------------------ evaluate / test
     def _project_back(self, boxes, geom):

@@ -243,3 +243,23 @@ def decode_nms(ctx, y13, y26, y52, image_hw, net_hw=(416, 416), anchors=COCO_ANC
     ctx.check(rc, 'fv_yolo_decode_nms')
     n = int(cnt.item())
     return dict(boxes=boxes[:n], objness=obj[:n], classes=cls[:n])
+
+
+def decode_nms_batch(ctx, y13, y26, y52, image_hw, net_hw=(416, 416), anchors=COCO_ANCHORS, obj_thresh=0.5, nms_thresh=0.45):
+    """A batch of images of one size: three (B,g,g,3*(5+nclass)) float32 CUDA tensors -> dict of CUDA tensors boxes (B,cap,4)
+    int32, objness (B,cap), classes (B,cap,nclass), count (B,) -- ONE launch pair for the batch, no host sync (the caller
+    copies the tensors out and reads count[b] entries of image b)."""
+    B, g = int(y13.shape[0]), int(y13.shape[-3])
+    nclass = int(y13.shape[-1]) // 3 - 5
+    cap = g * g + 2 * (2 * g) * (2 * g) + (4 * g) * (4 * g)
+    dev = y13.device
+    boxes = torch.empty((B, cap, 4), dtype=torch.int32, device=dev)
+    obj = torch.empty((B, cap), dtype=torch.float32, device=dev)
+    cls = torch.empty((B, cap, nclass), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    anc = (ctypes.c_float * 18)(*[float(v) for row in anchors for v in row])
+    rc = lib().fv_yolo_decode_nms_batch(ctx.handle, ptr(y13.contiguous()), ptr(y26.contiguous()), ptr(y52.contiguous()), B, g, nclass, anc,
+                                        float(obj_thresh), float(nms_thresh), int(net_hw[0]), int(net_hw[1]), int(image_hw[0]),
+                                        int(image_hw[1]), cap, ptr(boxes), ptr(obj), ptr(cls), ptr(cnt))
+    ctx.check(rc, 'fv_yolo_decode_nms_batch')
+    return dict(boxes=boxes, objness=obj, classes=cls, count=cnt)

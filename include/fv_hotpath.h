@@ -386,6 +386,14 @@ int fv_yolo_decode_nms(fv_ctx* ctx, const float* y13, const float* y26, const fl
                        int image_h, int image_w, int capacity, int32_t* boxes, float* objness, float* classes,
                        int32_t* count);
 
+/* The same for a BATCH of images of one size (the driver loop of yd.py:596-604 runs the chain image by image): outputs
+ * [nimg][g][g][3*(5+nclass)] per scale, boxes [nimg][capacity][4], objness [nimg][capacity], classes [nimg][capacity][nclass],
+ * count [nimg] -- one launch pair for the whole batch (workgroup = image in the decode, (class, image) in the NMS). */
+int fv_yolo_decode_nms_batch(fv_ctx* ctx, const float* y13, const float* y26, const float* y52, int nimg, int grid0, int nclass,
+                             const float* anchors18, float obj_thresh, double nms_thresh, int net_h, int net_w,
+                             int image_h, int image_w, int capacity, int32_t* boxes, float* objness, float* classes,
+                             int32_t* count);
+
 /* fd_loss (fd.py:59-64) -- DEFINED BUT NEVER USED by the reference (every compile() passes
  * loss='mse', fd.py:335/366/370/381); provided as an operator only, not wired into fv_train_step.
  * yp, yt [cells][6]; per cell (BCE(y0,p0) + mean_{c=1..4} sqrt((y_c-p_c)^2) + BCE(y5,p5))/3 with

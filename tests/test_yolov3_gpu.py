@@ -161,6 +161,34 @@ def test_decode_nms_properties_at_full_size(model):
         assert not np.any(iou >= 0.5)
 
 
+@pytest.mark.parametrize('nclass,gsz', [(1, 13), (4, 13), (80, 13), (1, 3)])
+def test_batched_decode_nms_equals_the_per_image_calls(model, nclass, gsz):
+    """fv_yolo_decode_nms_batch (one launch pair per batch; yd.py:596-604 loops over the images) returns, image by image, exactly
+    what the per-image call -- the one pinned by the reference goldens above -- returns: boxes, objectness, class probabilities
+    after NMS and the count, bit for bit; images with no candidate included."""
+    from face_vijnana_yolov3_amd.yolov3 import decode_nms, decode_nms_batch
+    rng = np.random.default_rng(nclass * 100 + gsz)
+    B, C = 5, 3 * (5 + nclass)
+    ys = []
+    for g in (gsz, 2 * gsz, 4 * gsz):
+        a = rng.normal(0, 1.0, (B, g, g, C)).astype(np.float32)
+        a5 = a.reshape(B, g, g, 3, 5 + nclass)
+        a5[..., 4] -= 1.0
+        a5[..., 2:4] *= 0.3
+        a5[3, ..., 4] = -20.0                                    # image 3: nothing passes the objectness threshold
+        ys.append(torch.from_numpy(a).cuda())
+    S = 32 * gsz
+    rb = decode_nms_batch(model.ctx, ys[0], ys[1], ys[2], (S, S), (S, S), obj_thresh=0.5, nms_thresh=0.45)
+    cnt = rb['count'].cpu().numpy()
+    assert cnt[3] == 0 and cnt.max() > 10
+    for b in range(B):
+        r1 = decode_nms(model.ctx, ys[0][b], ys[1][b], ys[2][b], (S, S), (S, S), obj_thresh=0.5, nms_thresh=0.45)
+        n = int(cnt[b])
+        assert r1['boxes'].shape[0] == n
+        assert torch.equal(rb['boxes'][b, :n], r1['boxes']) and torch.equal(rb['objness'][b, :n], r1['objness'])
+        assert torch.equal(rb['classes'][b, :n], r1['classes'])
+
+
 # ------------------------------------------------------------------------------------------ training (SURVEY 8f row 4)
 def _train_setup(out_ch, B, S, seed):
     from oracle import net_oracle as no

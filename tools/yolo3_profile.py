@@ -5,7 +5,7 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
     from face_vijnana_yolov3_amd.yolov3 import Yolov3
-    B, S = 16, 416
+    B, S = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), 416
     m = Yolov3(0, out_channels=255); m.init_synthetic(3)
     g = torch.Generator().manual_seed(4)
     x = torch.rand((B, S, S, 3), generator=g).cuda()
@@ -13,7 +13,7 @@ def main():
     for _ in range(2): m.train_on_batch(x, tg, 1e-4, 0.9, 0.999)
     torch.cuda.synchronize()
     m.ctx.set_overlap(False)
-    m.ctx.profile(True)
+    m.ctx.profile(True, shapes=len(sys.argv) > 1)
     for _ in range(2): m.train_on_batch(x, tg, 1e-4, 0.9, 0.999)
     prof = m.ctx.profile_collect(); m.ctx.profile(False)
     tot = 0
