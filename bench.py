@@ -68,8 +68,6 @@ def parse():
     ap.add_argument('--no-loader', action='store_true', help='skip the loader-inclusive measurement')
     ap.add_argument('--no-three-scale', action='store_true', help='skip the three-scale training measurement')
     ap.add_argument('--loader-steps', type=int, default=16)
-    ap.add_argument('--child-three-scale', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--child-loader', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -161,7 +159,7 @@ def cpu_baseline(batch, image_size, budget_s=45.0):
                                        'config-4 frames on one core' % nf))
 
 
-def detect_bench(eng, x40):
+def detect_bench(eng, x40, variants=False):
     """BASELINE metric 2, detect-path ms/img (fd.py:885-949 = predict + decode/NMS/top-k):
     batch 1 as the reference's evaluate loop calls it, batch 40, and config 4 (post-processing alone
     on 10k synthetic head outputs).  Device-side times (stream-ordered, one sync at the end)."""
@@ -194,9 +192,20 @@ def detect_bench(eng, x40):
     head[..., 1:3] = rng.uniform(0, 1, (10000, g, g, 2)); head[..., 3:5] = rng.uniform(0, 0.3, (10000, g, g, 2))
     hd = torch.from_numpy(head).cuda()
     tpp = timed(lambda: decode_nms(eng.ctx, hd, S, 0.5, 0.5, 60), 10)
-    return dict(unit='ms/img', batch1_device=round(t1, 4), batch1_end_to_end=round(e2e, 4),
-                batch40_device=round(t40 / x40.shape[0], 4), postproc_10k_frames=round(tpp / 10000, 6),
-                postproc_10k_total_ms=round(tpp, 3))
+    out = dict(unit='ms/img', batch1_device=round(t1, 4), batch1_end_to_end=round(e2e, 4),
+               batch40_device=round(t40 / x40.shape[0], 4), postproc_10k_frames=round(tpp / 10000, 6),
+               postproc_10k_total_ms=round(tpp, 3))
+    if variants:
+        # the two opt-in forms of the batch-1 forward, for the record (both measure at parity with the per-layer launches)
+        try:
+            eng.ctx.set_infer_persist(1)
+            out['batch1_device_one_launch'] = round(timed(lambda: one(x1), 20), 4)
+            eng.ctx.infer_persist_status()
+            eng.ctx.set_infer_persist(0); eng.ctx.set_fuse_finish1x1(True)
+            out['batch1_device_fused_finish_1x1'] = round(timed(lambda: one(x1), 20), 4)
+        finally:
+            eng.ctx.set_infer_persist(0); eng.ctx.set_fuse_finish1x1(False)
+    return out
 
 
 def loader_bench(eng, trainer, B, S, steps):
@@ -267,34 +276,7 @@ def loader_bench(eng, trainer, B, S, steps):
                      'and batch k+1 staged while step k runs; loader_only_pillow = the same loader with the whole decode in Pillow on the host' % n_img)
 
 
-def loader_child(args):
-    """`--child-loader`: the loader-inclusive section in a process of its own (the same late-in-process slowdown as the three-scale
-    section: 55.3-56.0 ms per step measured after the detect / test() sections of the parent against 53.3 in a fresh process,
-    tools/pipeline_probe.py); also times the resident-input step in THIS process, so the two are comparable."""
-    import torch
-    from face_vijnana_yolov3_amd import data
-    from face_vijnana_yolov3_amd.engine import Engine
-    from face_vijnana_yolov3_amd.parallel import DataParallelTrainer
-    B, S = args.batch, args.image_size
-    eng = Engine(0)
-    eng.init_synthetic(seed=7)
-    trainer = DataParallelTrainer(eng, world_size=1, rank=0)
-    x = torch.rand((B, S, S, 3), generator=torch.Generator().manual_seed(1234)).cuda()
-    y = torch.from_numpy(data.synth_gt_batch(B, S, seed=1234)).cuda()
-    for _ in range(8):
-        trainer.train_on_batch(x, y, **HPS)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.loader_steps):
-        trainer.train_on_batch(x, y, **HPS)
-    torch.cuda.synchronize()
-    resident = (time.perf_counter() - t0) / args.loader_steps * 1e3
-    out = loader_bench(eng, trainer, B, S, args.loader_steps)
-    out['resident_input_ms_per_step_same_process'] = round(resident, 3)
-    return out
-
-
-def test_loop_bench(device, S, n_img=128):
+def test_loop_bench(device, S, n_img=128, head='single'):
     """FaceDetector.test() end to end (fd.py:783-883: JPEG decode -> letterbox -> predict -> decode/NMS/top-k -> back-projection
     -> csv rows) on a synthetic UCCS-format folder: images/sec at the reference's batch 1 and with the read-ahead batches of
     hps.eval_batch_size = 16 / 32 (face_detection.FaceDetector._detect_files; 32 is the default).  Wall clock, host work included."""
@@ -311,17 +293,23 @@ def test_loop_bench(device, S, n_img=128):
         conf = {'mode': 'test', 'raw_data_path': root, 'test_path': root, 'output_file_path': os.path.join(root, 'solution_fd.csv'),
                 'multi_gpu': False, 'num_gpus': 1, 'yolov3_base_model_load': False, 'model_loading': False,
                 'hps': dict(HPS, epochs=1, step=1, batch_size=40, face_conf_th=0.5, nms_iou_th=0.5, num_cands=60, loader_threads=16),
-                'nn_arch': {'image_size': S, 'bb_info_c_size': 6}}
+                'nn_arch': {'image_size': S, 'bb_info_c_size': 6, 'head': head}}
         dbg, face_detection.DEBUG = face_detection.DEBUG, False
         try:
             import contextlib, io
             with contextlib.redirect_stdout(io.StringIO()):
                 fd = face_detection.FaceDetector(conf, device)
-            d = fd.model.layers[-1]                       # a head that fires on a few cells, so that rows are written
-            fd.model.params[d['w_off']:d['beta_off']] *= 0.05
-            fd.model.params[d['beta_off']] = 0.3; fd.model.params[d['beta_off'] + 5] = 0.3
+            if head == 'single':
+                d = fd.model.layers[-1]                       # a head that fires on a few cells, so that rows are written
+                fd.model.params[d['w_off']:d['beta_off']] *= 0.05
+                fd.model.params[d['beta_off']] = 0.3; fd.model.params[d['beta_off'] + 5] = 0.3
+            else:
+                for d in fd.model.layers:                     # the three detection convs: objectness logits around -2, a few cells fire
+                    if not d['has_bn']:
+                        fd.model.params[d['w_off']:d['beta_off']] *= 0.05
+                        fd.model.params[d['beta_off'] + 4:d['beta_off'] + d['cout']:6] = -2.0
             out = {}
-            for bs in (1, 16, 32):
+            for bs in ((1, 16, 32) if head == 'single' else (16, 32)):
                 conf['hps']['eval_batch_size'] = bs
                 fd.test()                                 # warm-up (workspace, file cache)
                 t0 = time.perf_counter(); fd.test(); dt = time.perf_counter() - t0
@@ -329,14 +317,17 @@ def test_loop_bench(device, S, n_img=128):
             rows = sum(1 for _ in open(conf['output_file_path']))
         finally:
             face_detection.DEBUG = dbg
+    if head != 'single':
+        return dict(unit='images/sec', eval_batch_16=out['batch16'], eval_batch_32=out['batch32'], images=n_img, csv_rows=rows,
+                    path='FaceDetector.test() with nn_arch.head = three_scale: fv_yolov3_forward + fv_yolo_decode_nms_batch (one launch pair per batch)')
     return dict(unit='images/sec', eval_batch_1=out['batch1'], eval_batch_16=out['batch16'], eval_batch_32=out['batch32'], images=n_img, csv_rows=rows,
                 path='FaceDetector.test(): %d synthetic JPEGs (768x1024 .. 720x1280), Huffman decoding on 16 host threads into reused pinned buffers one batch '
                      'ahead, fv_jpeg_reconstruct_batch, fv_letterbox_batch, fv_forward_infer, fv_decode_nms, back-projection, csv' % n_img)
 
 
-def three_scale_bench(device, S, B=16, steps=3):
+def three_scale_bench(device, S, B=PER_GPU_BATCH, steps=3):
     """one training step of the full three-scale YOLOv3 graph (75 convs, two upsample+concat routes,
-    255 output channels, the build's objectness/box/class loss, Adam) -- device-resident synthetic batch.  A secondary
+    255 output channels, the build's objectness/box/class loss, Adam) at the headline's per-GPU batch -- device-resident synthetic batch.  A secondary
     number beside `value`; weight-gradients overlap the data-gradient chain on the side stream as in fv_train_step."""
     import torch
     from face_vijnana_yolov3_amd.yolov3 import Yolov3
@@ -464,12 +455,6 @@ def self_launch(args):
 
 def main():
     args = parse()
-    if args.child_three_scale:                     # helper mode of the parent's three_scale_train section
-        print(json.dumps(three_scale_bench(0, args.image_size, steps=5)), flush=True)
-        return
-    if args.child_loader:                          # helper mode of the parent's loader_inclusive section
-        print(json.dumps(loader_child(args)), flush=True)
-        return
     if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.spawn):
         sys.exit(self_launch(args))              # nothing above touched the GPU: the children own the devices
     # Rank 0's JSON line is the ONLY thing on stdout: C libraries write to fd 1 too (RCCL prints its version banner there at
@@ -609,26 +594,39 @@ def main():
         trainer.barrier()
     out = None
     if rank == 0:
-        detect = None if args.no_detect else detect_bench(eng, x)
+        detect = None if args.no_detect else detect_bench(eng, x, variants=(world == 1))
         if detect is not None and world == 1 and not args.no_loader:
             detect['test_loop'] = test_loop_bench(local_rank, S)
+            detect['test_loop_three_scale_head'] = test_loop_bench(local_rank, S, n_img=64, head='three_scale')
+        # The secondary sections run IN this process again.  Round 3 moved them into fresh child processes because steps measured
+        # late in a process had run 13-30 % slow (three-scale 31.6 -> 41 ms, base 53 -> 60 ms); in round 4 that slowdown reproduced
+        # with none of: the original reproducer, these sections in any order, contexts created late, pinned-memory churn
+        # (profiles/r04_slowdown_probe.txt: every step within 1 % of its fresh-process time).  `process_history_check` below
+        # re-measures the headline step at the very end of this process, so a recurrence shows up in the line itself.
         loader = None
         if world == 1 and not args.no_loader:
-            import subprocess                # in a fresh child process, like the three-scale section below (loader_child)
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--child-loader', '--image-size', str(S), '--batch', str(B),
-                                '--loader-steps', str(args.loader_steps)], capture_output=True, text=True, timeout=900)
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"value"')]
-            loader = json.loads(line[-1]) if r.returncode == 0 and line else dict(error=(r.stderr or r.stdout)[-400:])
+            loader = loader_bench(eng, trainer, B, S, args.loader_steps)
         three = None
         if world == 1 and not args.no_three_scale and not args.no_detect:
-            # in a FRESH child process: measured in this one, after the other sections, the same step ran 41 instead of 31.6 ms
-            # (tools/stream_env_probe.py: not the stream pool, not RCCL, not further contexts -- a 10 GB workspace allocated late
-            # into a fragmented address space is the remaining suspect); this process only waits meanwhile
-            import subprocess
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--child-three-scale', '--image-size', str(S)],
-                               capture_output=True, text=True, timeout=600)
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"value"')]
-            three = json.loads(line[-1]) if r.returncode == 0 and line else dict(error=(r.stderr or r.stdout)[-400:])
+            three = three_scale_bench(local_rank, S, B=B, steps=5)
+            three['batch16'] = {k: v for k, v in three_scale_bench(local_rank, S, B=16, steps=5).items()
+                                if k in ('value', 'ms_per_step', 'step_tflops', 'frac_of_fp32_mfma_peak')}
+        history = None
+        if world == 1 and args.profile_steps > 0:
+            torch.cuda.synchronize()
+            late = []
+            for _ in range(3):
+                step()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+            ev[0].record()
+            for i in range(10):
+                step(); ev[i + 1].record()
+            torch.cuda.synchronize()
+            late = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(10))
+            late_ms = 0.5 * (late[4] + late[5])
+            history = dict(fresh_median_ms_per_step=round(median_ms, 3), late_median_ms_per_step=round(late_ms, 3),
+                           ratio=round(late_ms / median_ms, 4),
+                           note='the headline step re-timed (10 steps, median) after every other section of this process has run')
         dom_name, dom = dominant(prof)
         roofline = None
         traffic, traffic_source = pmc_traffic(B, S)
@@ -671,6 +669,7 @@ def main():
             'detect': detect,
             'loader_inclusive': loader,
             'three_scale_train': three,
+            'process_history_check': history,
             'multi_gpu': multi,
             'kernels': kernels,
         }

@@ -236,14 +236,16 @@ class FaceDetector(object):
 
     def _three_scale_boxes(self, host, b):
         """Image b of a decoded batch -> detect()'s own tail (fd.py:942-947): boxes in network pixels, score > 0, ascending score, at
-        most num_cands."""
+        most num_cands.  The selection runs on the arrays (BoundBox.get_score: the probability of the arg-max class, capped at 1);
+        only the <= num_cands survivors become BoundBox objects -- a frame can hold thousands of candidates."""
         n = int(host['count'][b])
         bx = host['boxes'][b, :n].numpy().astype(np.int64); ob = host['objness'][b, :n].numpy(); cl = host['classes'][b, :n].numpy()
-        boxes = [BoundBox(bx[k, 0], bx[k, 1], bx[k, 2], bx[k, 3], objness=ob[k], classes=list(cl[k])) for k in range(n)]
-        boxes = [bb for bb in boxes if bb.get_score() > 0]
-        scores = np.array([bb.get_score() for bb in boxes], np.float32)
-        order = np.argsort(scores, kind='stable')
-        return [boxes[i] for i in order[:self.hps['num_cands']]]
+        if n == 0:
+            return []
+        score = np.minimum(cl[np.arange(n), np.argmax(cl, axis=1)], np.float32(1.0))
+        keep = np.nonzero(score > 0)[0]
+        keep = keep[np.argsort(score[keep], kind='stable')][:self.hps['num_cands']]
+        return [BoundBox(bx[k, 0], bx[k, 1], bx[k, 2], bx[k, 3], objness=ob[k], classes=list(cl[k])) for k in keep]
 
     # ------------------------------------------------------------------ evaluate / test
     def _project_back(self, boxes, geom):
