@@ -430,28 +430,51 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const F
         const bool bnred = (a.epi & FV_EPI_BNRED) != 0;
         BnRedAcc br;                                 // NTH % C4 == 0: a thread keeps its 4 columns over the rows
         br.init(a, n0 + (tid % C4) * 4, bnred && n0 + (tid % C4) * 4 < a.Nout);
+        // The tile leaves in groups of four pieces per thread: the global loads of a group (the residual addend; z of the fused
+        // BN-backward reduction) are ALL issued before the first of them is used.  Piece by piece -- load, wait, combine, store --
+        // every one of the BM * C4 / NTH pieces paid a full memory round trip (eight s_waitcnt vmcnt(0) in a row): ~10 us per tile,
+        // which is most of a 1x1 data-gradient tile's life (4 - 8 K steps).  Rows outside the problem load from row 0 (in range,
+        // unused).
+        constexpr int NP = BM * C4 / NTH, GP = NP < 4 ? NP : 4;
+        static_assert(NP % GP == 0, "epilogue grouping");
+        const bool addon = (a.epi & FV_EPI_ADD) != 0;
 #pragma unroll
-        for (int p = 0; p < BM * C4 / NTH; ++p) {
-            const int f = tid + NTH * p, row = f / C4, c4 = (f % C4) * 4;
-            const int off = rowoff[row], n = n0 + c4;
-            if (off >= 0 && n < a.Nout) {
-                float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (bnred) zv = *reinterpret_cast<const float4*>(a.bn_z + off + n);
-                float4 v = *reinterpret_cast<const float4*>(&Cs[row * BN + c4]);
-                if (a.epi & FV_EPI_AFFINE) {
-                    if (a.scale) { const float4 s = *reinterpret_cast<const float4*>(a.scale + n); v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w; }
-                    if (a.shift) { const float4 s = *reinterpret_cast<const float4*>(a.shift + n); v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+        for (int p0 = 0; p0 < NP; p0 += GP) {
+            int offn[GP]; bool okp[GP];
+            float4 zq[GP], aq[GP];
+#pragma unroll
+            for (int q = 0; q < GP; ++q) {
+                const int f = tid + NTH * (p0 + q), row = f / C4, c4 = (f % C4) * 4;
+                const int off = rowoff[row], n = n0 + c4;
+                okp[q] = off >= 0 && n < a.Nout;
+                offn[q] = okp[q] ? off + n : 0;
+            }
+            if (bnred) {
+#pragma unroll
+                for (int q = 0; q < GP; ++q) zq[q] = *reinterpret_cast<const float4*>(a.bn_z + offn[q]);
+            }
+            if (addon) {
+#pragma unroll
+                for (int q = 0; q < GP; ++q) aq[q] = *reinterpret_cast<const float4*>(a.addend + offn[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < GP; ++q) {
+                const int f = tid + NTH * (p0 + q), row = f / C4, c4 = (f % C4) * 4;
+                const int n = n0 + c4;
+                if (okp[q]) {
+                    float4 v = *reinterpret_cast<const float4*>(&Cs[row * BN + c4]);
+                    if (a.epi & FV_EPI_AFFINE) {
+                        if (a.scale) { const float4 s = *reinterpret_cast<const float4*>(a.scale + n); v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w; }
+                        if (a.shift) { const float4 s = *reinterpret_cast<const float4*>(a.shift + n); v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+                    }
+                    if (a.epi & FV_EPI_LEAKY) {
+                        v.x = v.x > 0.f ? v.x : v.x * a.leaky; v.y = v.y > 0.f ? v.y : v.y * a.leaky;
+                        v.z = v.z > 0.f ? v.z : v.z * a.leaky; v.w = v.w > 0.f ? v.w : v.w * a.leaky;
+                    }
+                    if (addon) { v.x += aq[q].x; v.y += aq[q].y; v.z += aq[q].z; v.w += aq[q].w; }
+                    *reinterpret_cast<float4*>(outp + offn[q]) = v;
+                    if (bnred) br.add(v, zq[q], a.bn_leaky);
                 }
-                if (a.epi & FV_EPI_LEAKY) {
-                    v.x = v.x > 0.f ? v.x : v.x * a.leaky; v.y = v.y > 0.f ? v.y : v.y * a.leaky;
-                    v.z = v.z > 0.f ? v.z : v.z * a.leaky; v.w = v.w > 0.f ? v.w : v.w * a.leaky;
-                }
-                if (a.epi & FV_EPI_ADD) {
-                    const float4 s = *reinterpret_cast<const float4*>(a.addend + off + n);
-                    v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
-                }
-                *reinterpret_cast<float4*>(outp + off + n) = v;
-                if (bnred) br.add(v, zv, a.bn_leaky);
             }
         }
         if (bnred) bnred_flush<BN, NTH>(a, br, smem + BM * BN, n0, mt + cls * (int)(gridDim.x / NT));
