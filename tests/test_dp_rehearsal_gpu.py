@@ -129,3 +129,57 @@ def test_two_ranks_match_the_merged_batch_oracle(tmp_path):
     p1 = torch.from_numpy(np.load(tmp_path / 'p1.npy')).double()
     rp, _, _ = no.keras_adam(p0.double(), got, torch.zeros_like(got), torch.zeros_like(got), 0, 1e-4, 0.99, 0.99)
     torch.testing.assert_close(p1, rp, rtol=1e-6, atol=2e-7)
+
+
+AUTO_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+from face_vijnana_yolov3_amd.engine import Engine
+from face_vijnana_yolov3_amd.parallel import DataParallelTrainer, slice_batch
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+eng = Engine(0)
+eng.init_synthetic(seed=7)
+tr = DataParallelTrainer(eng, world_size=world, rank=rank, bucket_bytes=16 << 20)        # comm_mode 'auto'
+g = torch.Generator().manual_seed(100)
+x_all = torch.rand((5, 64, 64, 3), generator=g); y_all = torch.rand((5, 2, 2, 6), generator=g)
+lo, hi, weight = slice_batch(5, world, rank)
+x = x_all[lo:hi].cuda(); y = y_all[lo:hi].cuda()
+modes, n = [], 0
+while tr.calibrating:
+    tr.train_on_batch(x, y, 1e-4, 0.99, 0.99, weight=weight)
+    modes.append(tr.comm_mode); n += 1
+    assert n < 100
+for _ in range(2):
+    tr.train_on_batch(x, y, 1e-4, 0.99, 0.99, weight=weight)
+torch.cuda.synchronize()
+np.savez(os.path.join(%(out)r, 'auto%%d.npz' %% rank), params=eng.params.cpu().numpy(), state=eng.state.cpu().numpy(), n=n,
+         chosen=tr.comm_mode, report=repr(tr.auto_report), modes=np.array(modes))
+tr.shutdown()
+'''
+
+
+def test_auto_comm_mode_calibration_runs_every_mode_on_two_ranks(tmp_path):
+    """comm_mode 'auto' with more than one rank (round 4): 3 warm-up steps, then 'wg', 'main', 'pg' over 1 + 8 steps each; the
+    times are max-reduced, so both ranks choose alike; 'wg' is kept unless another mode is more than 1 %% faster; every step of
+    the calibration is an ordinary training step, so the replicas stay bit-identical through all three modes."""
+    script = tmp_path / 'auto_worker.py'
+    script.write_text(AUTO_WORKER % dict(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, FV_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    env.pop('FV_COMM_STREAM', None)
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a = np.load(tmp_path / 'auto0.npz'); b = np.load(tmp_path / 'auto1.npz')
+    assert int(a['n']) == int(b['n']) == 3 + 3 * 9 + 1, (a['n'], b['n'])
+    assert str(a['chosen']) == str(b['chosen']) and str(a['chosen']) in ('wg', 'main', 'pg')
+    seen = list(a['modes'])
+    assert seen[:3] == ['wg'] * 3 and set(seen[3:12]) == {'wg'} and set(seen[12:21]) == {'main'} and set(seen[21:30]) == {'pg'}, seen
+    rep = eval(str(a['report']))
+    assert set(rep['ms_per_step']) == {'wg', 'main', 'pg'} and all(v > 0 for v in rep['ms_per_step'].values()) and rep['chosen'] == str(a['chosen'])
+    if rep['chosen'] != 'wg':
+        assert rep['ms_per_step'][rep['chosen']] < 0.99 * rep['ms_per_step']['wg']
+    assert np.array_equal(a['params'], b['params']) and np.array_equal(a['state'], b['state'])
+    assert np.isfinite(a['params']).all()
