@@ -50,6 +50,8 @@ struct fv_ctx {
     unsigned* persist_err_host = nullptr; // pinned host word: a workgroup that abandons a wait stores its code here
     unsigned long long* persist_trace = nullptr;   // optional per-phase wall-clock stamps of workgroup 0 (fv_infer_persist_trace)
     bool persist_trace_on = false;
+    long long persist_spin_limit = 0;     // FV_PERSIST_SPIN: polls before a device-side wait gives up (0 = default)
+    int persist_test_stall = -1;          // FV_PERSIST_TEST_STALL: test hook, a workgroup that never reaches the third barrier
     ~fv_ctx();
 };
 

@@ -35,6 +35,8 @@ struct FvPersistArgs {
     unsigned* err_host;             // pinned host copy of the error word (may be NULL)
     unsigned long long* trace;      // optional [3 * nphase + 1] wall-clock stamps of workgroup 0 (100 MHz); NULL: off
     double alg_flops;
+    unsigned spin_limit;            // polls before a wait gives up (0: the default, ~1 s)
+    int stall_wg;                   // test hook (FV_PERSIST_TEST_STALL): this workgroup leaves at the third barrier without arriving; -1: none
 };
 
 int fv_persist_sync_words(int total_tiles);

@@ -57,10 +57,10 @@ __device__ __forceinline__ unsigned ld_relaxed(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // lane 0 of a workgroup: poll *p until it reaches `target`.  false: gave up (limit, or another workgroup raised the error word)
-__device__ bool spin_until_ge(const unsigned* p, unsigned target, unsigned* err) {
+__device__ bool spin_until_ge(const unsigned* p, unsigned target, unsigned* err, unsigned limit) {
     for (unsigned it = 0;; ++it) {
         if (ld_relaxed(p) >= target) return true;
-        if (it >= SPIN_LIMIT) return false;
+        if (it >= limit) return false;
         if ((it & 31) == 31 && ld_relaxed(err) != 0) return false;
         __builtin_amdgcn_s_sleep(16);           // ~0.4 us between polls: a poll is a fabric request on a line other CUs are adding to
     }
@@ -91,7 +91,7 @@ __device__ bool grid_barrier(const FvPersistArgs& A, unsigned epoch, int* s_flag
                     __hip_atomic_store(A.sync + SYNC_GEN + k * SYNC_STRIDE, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        const bool ok = spin_until_ge(A.sync + SYNC_GEN + g * SYNC_STRIDE, epoch, A.sync + SYNC_ERR);
+        const bool ok = spin_until_ge(A.sync + SYNC_GEN + g * SYNC_STRIDE, epoch, A.sync + SYNC_ERR, A.spin_limit ? A.spin_limit : SPIN_LIMIT);
         if (!ok) raise_error(A, FV_PERSIST_ERR_BARRIER);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -363,7 +363,8 @@ __device__ __forceinline__ void conv_item(const FvPersistArgs& A, const FvPersis
 __device__ __forceinline__ bool reduce_item(const FvPersistArgs& A, const FvPersistPhase& P, const Bases& b, int tile, int slice, int* s_flag) {
     const int tid = threadIdx.x;
     if (tid == 0) {
-        const bool ok = spin_until_ge(A.sync + SYNC_TILES + (P.cnt_off + tile) * SYNC_STRIDE, (unsigned)P.ksplit, A.sync + SYNC_ERR);
+        const bool ok = spin_until_ge(A.sync + SYNC_TILES + (P.cnt_off + tile) * SYNC_STRIDE, (unsigned)P.ksplit, A.sync + SYNC_ERR,
+                                      A.spin_limit ? A.spin_limit : SPIN_LIMIT);
         if (!ok) raise_error(A, FV_PERSIST_ERR_TILE);
 #if FV_PERSIST_FENCES
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(NTH, 4) void infer_persist_kernel(const FvPersistAr
             }
         }
         if (A.trace && blockIdx.x == 0 && threadIdx.x == 0) A.trace[3 * ph + 2] = wall_clock64();
+        if (ph == 2 && (int)blockIdx.x == A.stall_wg) return;      // test hook: a workgroup that is lost before a barrier
         if (ph + 1 < A.nphase && !grid_barrier(A, (unsigned)(ph + 1), &s_flag)) return;
     }
     if (A.trace && blockIdx.x == 0 && threadIdx.x == 0) A.trace[3 * A.nphase] = wall_clock64();

@@ -362,6 +362,7 @@ static int persist_forward(fv_ctx* ctx, const Plan& p, const float* params, floa
     a.sync = p.psync; a.err_host = ctx->persist_err_host;
     a.trace = ctx->persist_trace_on ? ctx->persist_trace : nullptr;
     a.alg_flops = ctx->persist_flops;
+    a.spin_limit = (unsigned)ctx->persist_spin_limit; a.stall_wg = ctx->persist_test_stall;
     FV_HIP(ctx, hipMemsetAsync(p.psync, 0, (size_t)fv_persist_sync_words(ctx->persist_tiles) * sizeof(unsigned), ctx->stream));
     const int rc = fv_persist_launch(ctx, a, grid);
     if (rc == FV_ERR_HIP) {

@@ -96,3 +96,30 @@ def test_fused_finish_and_1x1_layer_is_bit_identical(eng, B, S):
     f1, h1 = eng.predict_base_device(x, with_head=True)
     eng.ctx.set_fuse_finish1x1(False)
     assert torch.equal(y1, y0) and torch.equal(f1, f0) and torch.equal(h1, y0)
+
+
+def test_a_lost_workgroup_ends_in_an_error_report_not_in_a_hang(monkeypatch):
+    """Every device-side wait of the one-launch forward is bounded.  Test hook: workgroup 5 leaves before the third layer barrier
+    (FV_PERSIST_TEST_STALL) and the waits give up after 20 000 polls (FV_PERSIST_SPIN; the default is ~1 s): the others time
+    out at that barrier, raise the error word and leave, the launch ENDS, fv_infer_persist_status reports it, the NEXT forward
+    reports it too if nobody asked, and the context keeps working on the per-layer path."""
+    from face_vijnana_yolov3_amd._lib import FvError
+    from face_vijnana_yolov3_amd.engine import Engine
+    monkeypatch.setenv('FV_PERSIST_TEST_STALL', '5')
+    monkeypatch.setenv('FV_PERSIST_SPIN', '20000')
+    e = Engine(0)                                     # the environment is read when the context is created
+    monkeypatch.delenv('FV_PERSIST_TEST_STALL'); monkeypatch.delenv('FV_PERSIST_SPIN')
+    e.init_synthetic(seed=7)
+    x = _x(1, 416)
+    e.ctx.set_infer_persist(0)
+    y0 = e.predict_device(x).clone()
+    e.ctx.set_infer_persist(1)
+    e.predict_device(x)
+    with pytest.raises(FvError, match='abandoned a wait'):
+        e.ctx.infer_persist_status()
+    e.predict_device(x)                               # again: this time nobody asks for the status ...
+    torch.cuda.synchronize()
+    with pytest.raises(FvError, match='abandoned a wait'):
+        e.predict_device(x)                           # ... and the next call reports it
+    e.ctx.set_infer_persist(0)
+    assert torch.equal(e.predict_device(x), y0)
