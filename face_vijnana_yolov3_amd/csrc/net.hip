@@ -399,7 +399,7 @@ static int forward_impl(fv_ctx* ctx, const float* params, const float* bn_state,
     const float* skip = nullptr;
     // One cooperative launch for layers PERSIST_FIRST .. head when the forward is in the small-M regime (infer_persist.hip)
     bool use_persist = ctx->infer_persist != 0 && y && !feat && p.pslab && p.psync;
-    if (use_persist && ctx->persist_err_host && *ctx->persist_err_host) {
+    if (ctx->persist_err_host && *ctx->persist_err_host) {       // whatever path this call takes: an earlier launch gave up a wait
         const unsigned code = *ctx->persist_err_host;
         *ctx->persist_err_host = 0;
         return fv_fail(ctx, FV_ERR_HIP, "forward_infer: an earlier one-launch forward abandoned a wait (code %u: %s); its output is invalid",
