@@ -117,7 +117,10 @@ int fv_set_conv_scratch(fv_ctx* ctx, void* buf, size_t bytes);
  * Measurement aid with no counterpart in the reference (it has no profiler hooks):
  * when enabled, every kernel launch of this library is bracketed by a HIP event pair on the
  * context's stream; fv_profile_collect synchronises and returns one aggregate per kernel with
- * the ALGORITHMIC flops / bytes of the launches (what bench.py's `roofline` is computed from). */
+ * the ALGORITHMIC flops / bytes of the launches (what bench.py's `roofline` is computed from).
+ * on = 2: the records of the matrix kernels additionally carry the launch's problem shape in the name ("conv_kernel<128,2,4,false>
+ * M108160 N256 K1152 r": rows, output channels, taps x input channels; s2 = stride-2 data-gradient, ks = K split, r = fused
+ * BN-backward reduction), i.e. one aggregate per kernel AND shape (names are cut at 63 characters). */
 typedef struct fv_profile_rec {
     char name[64];
     int64_t launches;
