@@ -201,6 +201,10 @@ def detect_bench(eng, x40, variants=False):
             eng.ctx.set_infer_persist(1)
             out['batch1_device_one_launch'] = round(timed(lambda: one(x1), 20), 4)
             eng.ctx.infer_persist_status()
+            eng.ctx.set_infer_persist_cooperative(True)          # hipLaunchCooperativeKernel: ordered against the process's other queues
+            out['batch1_device_one_launch_cooperative'] = round(timed(lambda: one(x1), 20), 4)
+            eng.ctx.infer_persist_status()
+            eng.ctx.set_infer_persist_cooperative(False)
             eng.ctx.set_infer_persist(0); eng.ctx.set_fuse_finish1x1(True)
             out['batch1_device_fused_finish_1x1'] = round(timed(lambda: one(x1), 20), 4)
         finally:

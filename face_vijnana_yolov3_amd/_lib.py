@@ -68,6 +68,7 @@ def _declare(L):
         'fv_set_conv_scratch': (i32, [vp, vp, sz]),
         'fv_set_infer_persist': (i32, [vp, i32, i32]),
         'fv_set_fuse_finish1x1': (i32, [vp, i32]),
+        'fv_set_infer_persist_cooperative': (i32, [vp, i32]),
         'fv_infer_persist_status': (i32, [vp]),
         'fv_infer_persist_trace': (i32, [vp, i32, ctypes.POINTER(f64), i32, ctypes.POINTER(i32)]),
         'fv_set_conv0_direct': (i32, [vp, i32]),
@@ -194,6 +195,10 @@ class Context:
         """fv_set_infer_persist: 0 per-layer launches, 1 one cooperative launch for the small-M forward (default), 2 the same with the
         per-layer path's K-split plan (bit-identical to 0)."""
         self.check(lib().fv_set_infer_persist(self._h, int(mode), int(grid)), 'fv_set_infer_persist')
+
+    def set_infer_persist_cooperative(self, on):
+        """One-launch forward through hipLaunchCooperativeKernel (True) or as a plain launch behind the library's own occupancy check (default)."""
+        self.check(lib().fv_set_infer_persist_cooperative(self._h, 1 if on else 0), 'fv_set_infer_persist_cooperative')
 
     def set_fuse_finish1x1(self, on):
         self.check(lib().fv_set_fuse_finish1x1(self._h, 1 if on else 0), 'fv_set_fuse_finish1x1')

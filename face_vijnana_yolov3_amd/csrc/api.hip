@@ -126,6 +126,12 @@ int fv_set_infer_persist(fv_ctx* ctx, int mode, int grid) {
     return FV_OK;
 }
 
+int fv_set_infer_persist_cooperative(fv_ctx* ctx, int on) {
+    if (!ctx) return FV_ERR_INVALID;
+    ctx->persist_plain_launch = on == 0;
+    return FV_OK;
+}
+
 int fv_set_conv_scratch(fv_ctx* ctx, void* buf, size_t bytes) {
     if (!ctx) return FV_ERR_INVALID;
     ctx->tail_slab = buf ? (float*)buf : nullptr;
@@ -185,7 +191,7 @@ int fv_create(int device, void* stream, fv_ctx** out) {
     c->device = device;
     if (const char* e = getenv("FV_CONV_WAVES8")) c->conv_waves8 = e[0] != '0';
     if (const char* e = getenv("FV_FUSE_FINISH1X1")) c->fuse_finish1x1 = e[0] != '0';
-    if (const char* e = getenv("FV_PERSIST_PLAIN_LAUNCH")) c->persist_plain_launch = e[0] != '0';
+    if (const char* e = getenv("FV_PERSIST_COOP")) c->persist_plain_launch = e[0] == '0';
     if (const char* e = getenv("FV_PERSIST_SPIN")) c->persist_spin_limit = atoll(e);
     if (const char* e = getenv("FV_PERSIST_TEST_STALL")) c->persist_test_stall = atoi(e);
     if (const char* e = getenv("FV_INFER_PERSIST")) c->infer_persist = e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;

@@ -51,7 +51,7 @@ struct fv_ctx {
     unsigned long long* persist_trace = nullptr;   // optional per-phase wall-clock stamps of workgroup 0 (fv_infer_persist_trace)
     bool persist_trace_on = false;
     long long persist_spin_limit = 0;     // FV_PERSIST_SPIN: polls before a device-side wait gives up (0 = default)
-    bool persist_plain_launch = false;    // FV_PERSIST_PLAIN_LAUNCH=1: plain launch + own occupancy check instead of hipLaunchCooperativeKernel
+    bool persist_plain_launch = true;     // plain launch + the library's own occupancy check; false (fv_set_infer_persist_cooperative, FV_PERSIST_COOP=1): hipLaunchCooperativeKernel
     int persist_test_stall = -1;          // FV_PERSIST_TEST_STALL: test hook, a workgroup that never reaches the third barrier
     ~fv_ctx();
 };

@@ -29,7 +29,8 @@ def test_one_launch_forward_equals_the_per_layer_launches(eng, B, S):
     x = _x(B, S)
     eng.ctx.set_infer_persist(0); eng.ctx.set_fuse_finish1x1(False)
     y0 = eng.predict_device(x).clone()
-    for grid in (0, 256, 512, 64):
+    for grid, coop in ((0, False), (256, True), (512, False), (64, True), (0, True)):
+        eng.ctx.set_infer_persist_cooperative(coop)          # plain launch behind the library's occupancy check | hipLaunchCooperativeKernel
         eng.ctx.set_infer_persist(2, grid)
         y2 = eng.predict_device(x).clone()
         eng.ctx.infer_persist_status()                       # synchronises; raises if a wait was abandoned on the device
@@ -39,7 +40,7 @@ def test_one_launch_forward_equals_the_per_layer_launches(eng, B, S):
         eng.ctx.infer_persist_status()
         assert torch.equal(y1, y1b), ('repeatable', grid)
         assert (y1 - y0).abs().max().item() <= 2e-5 * max(y0.abs().max().item(), 1e-3), grid
-    eng.ctx.set_infer_persist(0)
+    eng.ctx.set_infer_persist(0); eng.ctx.set_infer_persist_cooperative(False)
 
 
 def test_one_launch_forward_matches_the_oracle(eng):
