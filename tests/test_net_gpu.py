@@ -396,3 +396,35 @@ def test_overfits_one_fixed_batch(eng):
     assert all(np.isfinite(losses)) and bool(torch.isfinite(eng.params).all())
     assert losses[-1] < 0.05 * losses[0], (losses[0], losses[-1])
     assert min(losses[40:]) < min(losses[:20])
+
+
+def test_loss_weight_scales_every_gradient_and_is_validated(eng):
+    """fv_train_step's loss_weight (the slice's share n_r / N of a merged data-parallel batch, fd.py:358-371): dL/dy is scaled in
+    the loss kernel, so EVERY gradient of the step is weight x the plain one (to the float-atomic order of dW) while the loss
+    value stays the slice's own; weights outside (0, 1] are refused."""
+    from face_vijnana_yolov3_amd._lib import FvError
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand((3, 96, 96, 3), generator=g).cuda(); y = torch.rand((3, 3, 3, 6), generator=g).cuda()
+    p0, s0 = eng.params.clone(), eng.state.clone()
+    eng.grads = eng.m = eng.v = None
+    l1 = eng.forward_backward(x, y).clone(); g1 = eng.grads.clone()
+    eng.set_params(p0, s0)
+    l2 = eng.forward_backward(x, y, loss_weight=0.375).clone(); g2 = eng.grads.clone()
+    torch.cuda.synchronize()
+    assert l1.item() == l2.item()
+    assert ((g2 - 0.375 * g1).norm() / (0.375 * g1).norm()).item() <= 1e-5
+    d = eng.layers[-1]
+    assert torch.allclose(g2[d['beta_off']:d['beta_off'] + 6], 0.375 * g1[d['beta_off']:d['beta_off'] + 6], rtol=1e-6, atol=1e-12)   # head bias: loss kernel
+    for w in (0.0, -0.5, 1.5):
+        with pytest.raises(FvError):
+            eng.forward_backward(x, y, loss_weight=w)
+    eng.set_params(p0, s0)
+    eng.grads = eng.m = eng.v = None
+
+
+def test_fv_scale(eng):
+    v = torch.arange(35712, dtype=torch.float32, device='cuda') - 17000.0
+    want = v * 0.125
+    eng.ctx.scale(v, 0.125)
+    torch.cuda.synchronize()
+    assert torch.equal(v, want)
