@@ -24,3 +24,34 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+# The driver runs `pytest -m gpu -x`: one failing property / variant test must not hide the pinned parity evidence.  Order of the
+# GPU suite = (0) tests that compare the HIP path with reference-minted goldens, (1) HIP vs the oracle per operator, (2) HIP vs
+# the oracle for whole steps / the FaceDetector chain, (3) everything else (properties, variants, multi-rank rehearsals).
+# Inside a group the files keep their alphabetical order and the tests their order in the file.
+_GPU_ORDER = {
+    'test_postproc_gpu.py': 0,
+    'test_yolov3_gpu.py': 0,
+    'test_jpeg_gpu.py': 0,
+    'test_ops_gpu.py': 1,
+    'test_fused_slots_gpu.py': 1,
+    'test_net_gpu.py': 2,
+    'test_face_detector_gpu.py': 2,
+    'test_three_scale_e2e_gpu.py': 2,
+}
+# property / variant / long tests inside the parity files run with group 3
+_GPU_LATE = ('overfits', 'tail_split_on_off', 'side_stream', 'bucketed', 'loss_weight', 'rehearsal', 'eval_batch_size', 'two_ranks',
+             'starts_its_ranks')
+
+
+def pytest_collection_modifyitems(config, items):
+    def key(ix_item):
+        ix, it = ix_item
+        if it.get_closest_marker('gpu') is None:
+            return (-1, ix)
+        g = _GPU_ORDER.get(os.path.basename(str(it.fspath)), 3)
+        if any(s in it.name for s in _GPU_LATE):
+            g = 3
+        return (g, ix)
+    items[:] = [it for _, it in sorted(enumerate(items), key=key)]
