@@ -27,6 +27,30 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128;
 constexpr int BK = 32;
+
+// Phase stamps of every workgroup (tools/build_variant.sh stamps -DFV_CONV_STAMPS; tools/conv_phases.py): kernel entry, first
+// operand tile staged, K loop done, last store issued -- wall_clock64 (100 MHz, the same clock on every CU) + the hardware id.
+#ifdef FV_CONV_STAMPS
+constexpr int STAMP_WGS = 32768;
+__device__ unsigned long long g_stamps[STAMP_WGS * 5];
+#define FV_STAMP(k)                                                                                             \
+    do {                                                                                                        \
+        if (threadIdx.x == 0) {                                                                                 \
+            const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                 \
+            if (wg_ < STAMP_WGS) {                                                                              \
+                g_stamps[wg_ * 5 + (k)] = wall_clock64();                                                       \
+                if ((k) == 0) {                                                                                 \
+                    unsigned hw_, xcc_;                                                                         \
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                           \
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                         \
+                    g_stamps[wg_ * 5 + 4] = ((unsigned long long)xcc_ << 32) | hw_;                              \
+                }                                                                                               \
+            }                                                                                                   \
+        }                                                                                                       \
+    } while (0)
+#else
+#define FV_STAMP(k) do {} while (0)
+#endif
 constexpr int LDT = BK + 4;  // padded LDS row (dwords)
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -133,6 +157,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const F
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int cls = blockIdx.z;
+    FV_STAMP(0);
     const FvTaps& taps = a.taps[cls];
 
     const int NT = (a.Nout + BN - 1) / BN;
@@ -341,6 +366,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const F
                 stage(0);
             }
             __syncthreads();
+            FV_STAMP(1);
             auto body = [&](int s, auto odd) {
                 constexpr bool ODD = decltype(odd)::value;      // even steps (from s_begin): LDS 0, next staged from set 2
                 const float* Ac = As[ODD ? 1 : 0]; const float* Bc = Bs[ODD ? 1 : 0];
@@ -372,6 +398,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const F
     }
 
     // ------------------------------------------------------------------ epilogue
+    FV_STAMP(2);
     const int half = lane >> 5, lc = lane & 31;
     if (tail_part) {
         // K-slice of a tail tile: raw partial tile, tile-local [BM][BN] layout, to its slab
@@ -478,6 +505,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const F
             }
         }
         if (bnred) bnred_flush<BN, NTH>(a, br, smem + BM * BN, n0, mt + cls * (int)(gridDim.x / NT));
+        FV_STAMP(3);
         return;
     }
     // scalar path: output rows that are not 16-byte aligned (head: 6 channels; 255-channel detection convs)
@@ -624,6 +652,15 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
 }
 
 }  // namespace
+
+#ifdef FV_CONV_STAMPS
+extern "C" int fv_debug_conv_stamps(fv_ctx* ctx, unsigned long long* out, int nwg) {
+    if (!ctx || !out || nwg < 1 || nwg > STAMP_WGS) return FV_ERR_INVALID;
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FV_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)nwg * 5 * sizeof(unsigned long long)));
+    return FV_OK;
+}
+#endif
 
 int fv_conv_mtiles(int M, int Nout) { (void)Nout; return (M + BM - 1) / BM; }
 

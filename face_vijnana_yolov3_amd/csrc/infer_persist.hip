@@ -427,7 +427,9 @@ __device__ __forceinline__ bool reduce_item(const FvPersistArgs& A, const FvPers
     return true;
 }
 
-__global__ __launch_bounds__(NTH, 4) void infer_persist_kernel(const FvPersistArgs A) {
+// (NTH, 2): two waves per SIMD = ONE workgroup per CU, the configuration that is run (net.hip persist_forward): 151 VGPRs, no scratch;
+// with (NTH, 4) the 128-VGPR cap spilled 18 VGPRs (76 B/lane of scratch) into the tile loop
+__global__ __launch_bounds__(NTH, 2) void infer_persist_kernel(const FvPersistArgs A) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDT];
     __shared__ int rowoff[BM];
     __shared__ int s_flag;

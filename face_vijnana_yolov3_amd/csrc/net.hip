@@ -432,7 +432,9 @@ static int forward_impl(fv_ctx* ctx, const float* params, const float* bn_state,
             if (fuse) {
                 const auto& d1 = N.L[l + 1];
                 int iout1 = 0;
-                while (iout1 == iout) ++iout1;             // layer l+1 opens a block: its input (= out) is the block's skip tensor
+                // layer l+1 opens a block: its input (= out) is the block's skip tensor.  Its output must alias neither `out` nor -- when
+                // layer l closes a block (role 2) -- the skip tensor this same launch still reads in other workgroups
+                while (iout1 == iout || (d.role == 2 && iout1 == iskip)) ++iout1;
                 if (int rc = fv_ew_finish_conv1x1(ctx, p.slab, ks, rows * d.cout, p.scale[l], p.shift[l], d.role == 2 ? skip : nullptr, out,
                                                   params + d1.w_off, p.scale[l + 1], p.shift[l + 1], p.G[iout1], (int)rows, d.cout, d1.cout,
                                                   LEAKY)) return rc;

@@ -29,7 +29,7 @@ import json
 import os
 import platform
 import time
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import ThreadPoolExecutor, wait
 
 import numpy as np
 
@@ -37,6 +37,20 @@ from . import data
 from .postproc import BoundBox, PinnedRing, decode_nms, letterbox_batch_device, pack_images, to_boundboxes
 
 DEBUG = True
+
+
+def default_loader_threads():
+    """hps['loader_threads'] when the configuration does not set it: a quarter of the host's logical CPUs, at most 32, at least 4
+    (the reference asks for 4 or 8 Keras workers, fd.py:621-627; measured on a 128-CPU MI355X host: bench.py `test_loop` sweep)."""
+    return max(4, min(32, (os.cpu_count() or 16) // 4))
+
+
+def map_all(pool, fn, items):
+    """pool.map that returns only when EVERY task has finished, also when one raised (Executor.map stops waiting at the first
+    exception and leaves the running tasks writing into the buffer they were given); re-raises the first exception."""
+    futs = [pool.submit(fn, it) for it in items]
+    wait(futs)
+    return [f.result() for f in futs]
 
 
 class FaceDetector(object):
@@ -136,11 +150,15 @@ class FaceDetector(object):
         """The Darknet-53 base as a model of its own (fd.py:384-600: "partial yolo3 model from the input layer to the add_23
         layer"; the reference builds its detector around it, fd.py:344-352, and FaceIdentifier reuses it,
         face_identification.py:323).  Here: a view of THIS detector's base weights with `predict` (numpy, as Keras),
-        `predict_device` (CUDA tensor) and `save` (the yolov3_base.h5 layout, fd.py:598) -- fv_forward_base underneath."""
+        `predict_device` (CUDA tensor) and `save` (the yolov3_base.h5 layout, fd.py:598) -- fv_forward_base underneath.
+        Single-scale head: a live view of the detector's engine.  Three-scale head: a SNAPSHOT -- the base weights are copied into a
+        cached Engine at every access of the property (read it again after training)."""
         if self.three_scale:
             # the three-scale model keeps its base in the same flat layout at the same offsets: lend it to an Engine
             from .engine import Engine
-            eng = Engine(self.model.ctx.device)
+            eng = getattr(self, '_base_engine', None)
+            if eng is None:
+                eng = self._base_engine = Engine(self.model.ctx.device)     # one Engine, reused: only the weights are refreshed per access
             nb = eng.layers[-2]
             n_p, n_s = nb['beta_off'] + nb['cout'], nb['var_off'] + nb['cout']
             eng.params[:n_p].copy_(self.model.params[:n_p]); eng.state[:n_s].copy_(self.model.state[:n_s])
@@ -166,7 +184,7 @@ class FaceDetector(object):
         hp = self.hps
         steps = len(seq)
         rng = np.random.default_rng(0)
-        feeder = BatchFeeder(seq, self.world, self.rank, int(hp.get('loader_threads', 8)))
+        feeder = BatchFeeder(seq, self.world, self.rank, int(hp.get('loader_threads', default_loader_threads())))
         log_every = max(1, int(hp.get('log_every', 1)))
         for epoch in range(hp['epochs']):
             order = rng.permutation(steps)  # Keras fit_generator shuffles batch order (shuffle=True)
@@ -285,7 +303,7 @@ class FaceDetector(object):
         chunks = [files[i:i + bs] for i in range(0, len(files), bs)]
         if not chunks:
             return
-        threads = max(1, min(bs, int(self.hps.get('loader_threads', 8))))
+        threads = max(1, min(bs, int(self.hps.get('loader_threads', default_loader_threads()))))
         use_jpeg = not need_raw and bool(self.hps.get('device_jpeg', True))
         if getattr(self, '_eval_ring', None) is None:
             self._eval_ring = PinnedRing(3)          # kept across evaluate()/test() calls: page-locking is the expensive part
@@ -302,12 +320,13 @@ class FaceDetector(object):
                         buf = ring.take(2 * plan.total_coefs).view(torch.int16)     # decoded straight into a reused pinned buffer
                         view = buf.numpy()
                         try:
-                            list(pool.map(lambda i: jpeg.entropy_decode(datas[i], infos[i], view[plan.coef_off[i]:plan.coef_off[i] + int(infos[i].total_coefs)]),
-                                          range(len(chunk))))
+                            map_all(pool, lambda i: jpeg.entropy_decode(datas[i], infos[i], view[plan.coef_off[i]:plan.coef_off[i] + int(infos[i].total_coefs)]),
+                                    range(len(chunk)))
                             return None, ('jpeg', buf, plan)
                         except ValueError:
                             # damaged scan data (a bad Huffman code, a run past the block): libjpeg -- the reference's reader
-                            # (skimage.io.imread, fd.py:798) -- only warns and returns an image; so the batch goes through Pillow
+                            # (skimage.io.imread, fd.py:798) -- only warns and returns an image; so the batch goes through Pillow.
+                            # map_all has waited for every decoder task: nothing writes into the slot any more
                             ring.untake()
                 raws = list(pool.map(data._pil_loader, chunk))
                 return raws, pack_images(raws, ring=ring)
@@ -398,7 +417,7 @@ class FaceDetector(object):
 
 class YoloV3BaseModel(object):
     """What FaceDetector.YOLOV3Base hands out: input (B,S,S,3) in [0,1] -> (B,S/32,S/32,1024), the output of the last
-    residual add of the Darknet-53 base (fd.py:384-600).  A live view of the engine's weights, not a copy."""
+    residual add of the Darknet-53 base (fd.py:384-600).  A view of the engine it was given (FaceDetector.YOLOV3Base says which)."""
     trainable = True                                   # fd.py:396, 597
 
     def __init__(self, engine):
@@ -454,10 +473,11 @@ class BatchFeeder(object):
             buf = torch.empty(plan.total_coefs, dtype=torch.int16)
         view = buf.numpy()
         try:
-            list(self.pool.map(lambda i: jpeg.entropy_decode(datas[i], infos[i], view[plan.coef_off[i]:plan.coef_off[i] + int(infos[i].total_coefs)]),
-                               range(len(names))))
+            map_all(self.pool, lambda i: jpeg.entropy_decode(datas[i], infos[i], view[plan.coef_off[i]:plan.coef_off[i] + int(infos[i].total_coefs)]),
+                    range(len(names)))
         except ValueError:
             # damaged scan data: libjpeg (the reference's reader, fd.py:112) warns and still returns an image -- Pillow path
+            # (every decoder task has finished: map_all waits for all of them before it raises)
             if slot is not None:
                 self.ring.untake()
             return None

@@ -1,7 +1,7 @@
-import sys, torch
+import os, sys, torch
 
 def main():
-    import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from face_vijnana_yolov3_amd.engine import Engine
     eng = Engine(0); eng.init_synthetic(seed=7)
     x = torch.rand((1,416,416,3), device='cuda')
@@ -19,6 +19,13 @@ def main():
     for k,v in sorted(p.items(), key=lambda kv:-kv[1]['ms']):
         print('%-34s launches/img %5.1f  ms/img %.4f  us/launch %.2f' % (k, v['launches']/10, v['ms']/10, v['ms']/v['launches']*1e3)); tot+=v['ms']/10
     print('sum of kernel ms/img', tot)
+    if os.environ.get('BS1_MAPS'):       # library map of this process: attributes the frames of an exit-time fault
+        with open(os.environ['BS1_MAPS'], 'w') as f:
+            for ln in open('/proc/self/maps'):
+                if 'r-xp' in ln or 'r--p' in ln:
+                    f.write(ln)
+    if os.environ.get('BS1_CLOSE'):      # release the context explicitly, before interpreter shutdown
+        eng.ctx.close()
 
 
 if __name__ == '__main__':
