@@ -159,7 +159,7 @@ def cpu_baseline(batch, image_size, budget_s=45.0):
                                        'config-4 frames on one core' % nf))
 
 
-def detect_bench(eng, x40, variants=False):
+def detect_bench(eng, x40):
     """BASELINE metric 2, detect-path ms/img (fd.py:885-949 = predict + decode/NMS/top-k):
     batch 1 as the reference's evaluate loop calls it, batch 40, and config 4 (post-processing alone
     on 10k synthetic head outputs).  Device-side times (stream-ordered, one sync at the end)."""
@@ -195,20 +195,6 @@ def detect_bench(eng, x40, variants=False):
     out = dict(unit='ms/img', batch1_device=round(t1, 4), batch1_end_to_end=round(e2e, 4),
                batch40_device=round(t40 / x40.shape[0], 4), postproc_10k_frames=round(tpp / 10000, 6),
                postproc_10k_total_ms=round(tpp, 3))
-    if variants:
-        # the two opt-in forms of the batch-1 forward, for the record (both measure at parity with the per-layer launches)
-        try:
-            eng.ctx.set_infer_persist(1)
-            out['batch1_device_one_launch'] = round(timed(lambda: one(x1), 20), 4)
-            eng.ctx.infer_persist_status()
-            eng.ctx.set_infer_persist_cooperative(True)          # hipLaunchCooperativeKernel: ordered against the process's other queues
-            out['batch1_device_one_launch_cooperative'] = round(timed(lambda: one(x1), 20), 4)
-            eng.ctx.infer_persist_status()
-            eng.ctx.set_infer_persist_cooperative(False)
-            eng.ctx.set_infer_persist(0); eng.ctx.set_fuse_finish1x1(True)
-            out['batch1_device_fused_finish_1x1'] = round(timed(lambda: one(x1), 20), 4)
-        finally:
-            eng.ctx.set_infer_persist(0); eng.ctx.set_fuse_finish1x1(False)
     return out
 
 
@@ -280,23 +266,30 @@ def loader_bench(eng, trainer, B, S, steps):
                      'and batch k+1 staged while step k runs; loader_only_pillow = the same loader with the whole decode in Pillow on the host' % n_img)
 
 
-def test_loop_bench(device, S, n_img=128, head='single'):
+def test_loop_bench(device, S, n_img=256, head='single'):
     """FaceDetector.test() end to end (fd.py:783-883: JPEG decode -> letterbox -> predict -> decode/NMS/top-k -> back-projection
     -> csv rows) on a synthetic UCCS-format folder: images/sec at the reference's batch 1 and with the read-ahead batches of
-    hps.eval_batch_size = 16 / 32 (face_detection.FaceDetector._detect_files; 32 is the default).  Wall clock, host work included."""
+    hps.eval_batch_size = 16 / 32 (face_detection.FaceDetector._detect_files; 32 is the default), then at batch 32 for
+    hps.loader_threads = 8 / 16 / 32 / 64.  Wall clock, host work included.  n_img: the loop is a two-deep pipeline whose first
+    load and last forward overlap nothing -- with 64 images a batch of 32 is two chunks, i.e. all fill and drain (round 4's
+    three-scale 709 -> 537 img/s from batch 16 to 32 was that, not the kernels); 256 images = 8 chunks of 32."""
     import numpy as np
     from PIL import Image
     from face_vijnana_yolov3_amd import face_detection
     with tempfile.TemporaryDirectory() as root:
         rng = np.random.default_rng(0)
         sizes = [(768, 1024), (1024, 768), (720, 1280), (600, 800)]
-        for k in range(n_img):
+        base = []
+        for k in range(16):                                  # 16 distinct pictures, written n_img / 16 times each (file cache alike)
             h, w = sizes[k % len(sizes)]
             lo = rng.integers(0, 256, (h // 16 + 1, w // 16 + 1, 3), dtype=np.uint8)
-            Image.fromarray(lo).resize((w, h), Image.BICUBIC).save(os.path.join(root, 'img_%04d.jpg' % k), quality=90)
+            base.append(Image.fromarray(lo).resize((w, h), Image.BICUBIC))
+        for k in range(n_img):
+            base[k % 16].save(os.path.join(root, 'img_%04d.jpg' % k), quality=90)
+        default_threads = face_detection.default_loader_threads()
         conf = {'mode': 'test', 'raw_data_path': root, 'test_path': root, 'output_file_path': os.path.join(root, 'solution_fd.csv'),
                 'multi_gpu': False, 'num_gpus': 1, 'yolov3_base_model_load': False, 'model_loading': False,
-                'hps': dict(HPS, epochs=1, step=1, batch_size=40, face_conf_th=0.5, nms_iou_th=0.5, num_cands=60, loader_threads=16),
+                'hps': dict(HPS, epochs=1, step=1, batch_size=40, face_conf_th=0.5, nms_iou_th=0.5, num_cands=60, loader_threads=default_threads),
                 'nn_arch': {'image_size': S, 'bb_info_c_size': 6, 'head': head}}
         dbg, face_detection.DEBUG = face_detection.DEBUG, False
         try:
@@ -312,21 +305,88 @@ def test_loop_bench(device, S, n_img=128, head='single'):
                     if not d['has_bn']:
                         fd.model.params[d['w_off']:d['beta_off']] *= 0.05
                         fd.model.params[d['beta_off'] + 4:d['beta_off'] + d['cout']:6] = -2.0
+
+            def rate():
+                fd.test()                                 # warm-up (workspace, file cache)
+                t0 = time.perf_counter(); fd.test(); dt = time.perf_counter() - t0
+                return round(n_img / dt, 1)
             out = {}
             for bs in ((1, 16, 32) if head == 'single' else (16, 32)):
                 conf['hps']['eval_batch_size'] = bs
-                fd.test()                                 # warm-up (workspace, file cache)
-                t0 = time.perf_counter(); fd.test(); dt = time.perf_counter() - t0
-                out['batch%d' % bs] = round(n_img / dt, 1)
+                out['batch%d' % bs] = rate()
             rows = sum(1 for _ in open(conf['output_file_path']))
+            sweep = {}
+            if head == 'single':
+                conf['hps']['eval_batch_size'] = 32
+                for nt in (8, 16, 32, 64):
+                    conf['hps']['loader_threads'] = nt
+                    sweep[str(nt)] = rate()
         finally:
             face_detection.DEBUG = dbg
     if head != 'single':
         return dict(unit='images/sec', eval_batch_16=out['batch16'], eval_batch_32=out['batch32'], images=n_img, csv_rows=rows,
+                    loader_threads=default_threads,
                     path='FaceDetector.test() with nn_arch.head = three_scale: fv_yolov3_forward + fv_yolo_decode_nms_batch (one launch pair per batch)')
     return dict(unit='images/sec', eval_batch_1=out['batch1'], eval_batch_16=out['batch16'], eval_batch_32=out['batch32'], images=n_img, csv_rows=rows,
-                path='FaceDetector.test(): %d synthetic JPEGs (768x1024 .. 720x1280), Huffman decoding on 16 host threads into reused pinned buffers one batch '
-                     'ahead, fv_jpeg_reconstruct_batch, fv_letterbox_batch, fv_forward_infer, fv_decode_nms, back-projection, csv' % n_img)
+                loader_threads=default_threads, eval_batch_32_by_loader_threads=sweep, host_cpus=host_cpus(),
+                path='FaceDetector.test(): %d synthetic JPEGs (768x1024 .. 720x1280), Huffman decoding on hps.loader_threads host threads (default '
+                     'min(32, cpus / 4)) into reused pinned buffers one batch ahead, fv_jpeg_reconstruct_batch, fv_letterbox_batch, '
+                     'fv_forward_infer, fv_decode_nms, back-projection, csv' % n_img)
+
+
+def host_cpus():
+    """Logical CPUs of the host and the CPUs this process may actually run on (affinity mask / cgroup quota)."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None
+    quota = None
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        quota = None if q == 'max' else round(int(q) / int(per), 1)
+    except (OSError, ValueError):
+        pass
+    return dict(logical=os.cpu_count(), affinity=aff, cgroup_quota=quota)
+
+
+def config5_bench(device, B=16, S=608, steps=10):
+    """BASELINE config 5 at its per-GPU size: image_size 608, batch 16 (grid 19; the x8 data-parallel half is the driver's).
+    Its own Engine (the headline engine keeps its workspace), device-resident synthetic batch, median of `steps` steps."""
+    import torch
+    from face_vijnana_yolov3_amd import data
+    from face_vijnana_yolov3_amd.engine import Engine, train_flops_per_image
+    eng = Engine(device)
+    eng.init_synthetic(seed=7)
+    g = torch.Generator(device='cpu').manual_seed(608)
+    x = torch.rand((B, S, S, 3), generator=g).cuda(device)
+    y = torch.from_numpy(data.synth_gt_batch(B, S, seed=608)).cuda(device)
+    for _ in range(3):
+        loss = eng.train_on_batch(x, y, **HPS)
+    torch.cuda.synchronize(device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
+    for i in range(steps):
+        loss = eng.train_on_batch(x, y, **HPS); ev[i + 1].record()
+    torch.cuda.synchronize(device)
+    per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    ms = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
+    tf = train_flops_per_image(S) * B / (ms * 1e-3) / 1e12
+    xi = x[:1].contiguous()
+    for _ in range(3):
+        eng.predict_device(x); eng.predict_device(xi)
+    torch.cuda.synchronize(device)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    for _ in range(5):
+        eng.predict_device(x)
+    e1.record()
+    for _ in range(20):
+        eng.predict_device(xi)
+    e2.record(); torch.cuda.synchronize(device)
+    out = dict(value=round(B / (ms * 1e-3), 2), unit='images/sec', median_ms_per_step=round(ms, 3), batch=B, image_size=S, steps=steps,
+               step_tflops=round(tf, 2), frac_of_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 4), loss=float(loss.item()),
+               forward_infer_ms_per_img_batch16=round(e0.elapsed_time(e1) / 5 / B, 4), forward_infer_ms_per_img_batch1=round(e1.elapsed_time(e2) / 20, 4),
+               workload='FaceDetector mode=train image_size=608 batch_size=16 (BASELINE config 5, one GPU of the 16x8): fv_train_step + Adam')
+    del eng, x, y
+    torch.cuda.empty_cache()
+    return out
 
 
 def three_scale_bench(device, S, B=PER_GPU_BATCH, steps=3):
@@ -598,10 +658,10 @@ def main():
         trainer.barrier()
     out = None
     if rank == 0:
-        detect = None if args.no_detect else detect_bench(eng, x, variants=(world == 1))
+        detect = None if args.no_detect else detect_bench(eng, x)
         if detect is not None and world == 1 and not args.no_loader:
             detect['test_loop'] = test_loop_bench(local_rank, S)
-            detect['test_loop_three_scale_head'] = test_loop_bench(local_rank, S, n_img=64, head='three_scale')
+            detect['test_loop_three_scale_head'] = test_loop_bench(local_rank, S, n_img=256, head='three_scale')
         # The secondary sections run IN this process again.  Round 3 moved them into fresh child processes because steps measured
         # late in a process had run 13-30 % slow (three-scale 31.6 -> 41 ms, base 53 -> 60 ms); in round 4 that slowdown reproduced
         # with none of: the original reproducer, these sections in any order, contexts created late, pinned-memory churn
@@ -615,6 +675,9 @@ def main():
             three = three_scale_bench(local_rank, S, B=B, steps=5)
             three['batch16'] = {k: v for k, v in three_scale_bench(local_rank, S, B=16, steps=5).items()
                                 if k in ('value', 'ms_per_step', 'step_tflops', 'frac_of_fp32_mfma_peak')}
+        config5 = None
+        if world == 1 and not args.no_three_scale and not args.no_detect and (B, S) == (PER_GPU_BATCH, IMAGE_SIZE):
+            config5 = config5_bench(local_rank)
         history = None
         if world == 1 and args.profile_steps > 0:
             torch.cuda.synchronize()
@@ -673,6 +736,7 @@ def main():
             'detect': detect,
             'loader_inclusive': loader,
             'three_scale_train': three,
+            'config5_608_bs16': config5,
             'process_history_check': history,
             'multi_gpu': multi,
             'kernels': kernels,

@@ -66,11 +66,6 @@ def _declare(L):
         'fv_set_bucket_on_side': (i32, [vp, i32]),
         'fv_side_stream': (vp, [vp]),
         'fv_set_conv_scratch': (i32, [vp, vp, sz]),
-        'fv_set_infer_persist': (i32, [vp, i32, i32]),
-        'fv_set_fuse_finish1x1': (i32, [vp, i32]),
-        'fv_set_infer_persist_cooperative': (i32, [vp, i32]),
-        'fv_infer_persist_status': (i32, [vp]),
-        'fv_infer_persist_trace': (i32, [vp, i32, ctypes.POINTER(f64), i32, ctypes.POINTER(i32)]),
         'fv_set_conv0_direct': (i32, [vp, i32]),
         'fv_set_conv_waves8': (i32, [vp, i32]),
         'fv_set_conv_halo': (i32, [vp, i32]),
@@ -190,28 +185,6 @@ class Context:
 
     def set_conv0_direct(self, on):
         self.check(lib().fv_set_conv0_direct(self._h, 1 if on else 0), 'fv_set_conv0_direct')
-
-    def set_infer_persist(self, mode, grid=0):
-        """fv_set_infer_persist: 0 per-layer launches, 1 one cooperative launch for the small-M forward (default), 2 the same with the
-        per-layer path's K-split plan (bit-identical to 0)."""
-        self.check(lib().fv_set_infer_persist(self._h, int(mode), int(grid)), 'fv_set_infer_persist')
-
-    def set_infer_persist_cooperative(self, on):
-        """One-launch forward through hipLaunchCooperativeKernel (True) or as a plain launch behind the library's own occupancy check (default)."""
-        self.check(lib().fv_set_infer_persist_cooperative(self._h, 1 if on else 0), 'fv_set_infer_persist_cooperative')
-
-    def set_fuse_finish1x1(self, on):
-        self.check(lib().fv_set_fuse_finish1x1(self._h, 1 if on else 0), 'fv_set_fuse_finish1x1')
-
-    def infer_persist_status(self):
-        self.check(lib().fv_infer_persist_status(self._h), 'fv_infer_persist_status')
-
-    def infer_persist_trace(self, on, read=False):
-        """Switch the per-phase stamps of the one-launch forward on / off; read=True first returns those of the last launch (us)."""
-        buf = (ctypes.c_double * 256)(); n = ctypes.c_int(0)
-        self.check(lib().fv_infer_persist_trace(self._h, 1 if on else 0, buf if read else None, 256, ctypes.byref(n) if read else None),
-                   'fv_infer_persist_trace')
-        return [buf[i] for i in range(n.value)] if read else None
 
     def set_conv_scratch(self, tensor):
         """Lend device scratch (a torch tensor, kept alive here) to the per-operator conv calls."""

@@ -24,9 +24,6 @@ fv_ctx::~fv_ctx() {
         if (ev_wg[i]) (void)hipEventDestroy(ev_wg[i]);
     }
     if (side) (void)hipStreamDestroy(side);
-    if (persist_table) (void)hipFree(persist_table);
-    if (persist_err_host) (void)hipHostFree(persist_err_host);
-    if (persist_trace) (void)hipFree(persist_trace);
 }
 
 static hipEvent_t take_event(fv_ctx* c) {
@@ -113,25 +110,6 @@ int fv_set_conv0_direct(fv_ctx* ctx, int on) {
     return FV_OK;
 }
 
-int fv_set_fuse_finish1x1(fv_ctx* ctx, int on) {
-    if (!ctx) return FV_ERR_INVALID;
-    ctx->fuse_finish1x1 = on != 0;
-    return FV_OK;
-}
-
-int fv_set_infer_persist(fv_ctx* ctx, int mode, int grid) {
-    if (!ctx || mode < 0 || mode > 2 || grid < 0 || (grid % 8) != 0) return FV_ERR_INVALID;
-    ctx->infer_persist = mode;
-    ctx->persist_grid = grid;
-    return FV_OK;
-}
-
-int fv_set_infer_persist_cooperative(fv_ctx* ctx, int on) {
-    if (!ctx) return FV_ERR_INVALID;
-    ctx->persist_plain_launch = on == 0;
-    return FV_OK;
-}
-
 int fv_set_conv_scratch(fv_ctx* ctx, void* buf, size_t bytes) {
     if (!ctx) return FV_ERR_INVALID;
     ctx->tail_slab = buf ? (float*)buf : nullptr;
@@ -190,11 +168,6 @@ int fv_create(int device, void* stream, fv_ctx** out) {
     fv_ctx* c = new fv_ctx();
     c->device = device;
     if (const char* e = getenv("FV_CONV_WAVES8")) c->conv_waves8 = e[0] != '0';
-    if (const char* e = getenv("FV_FUSE_FINISH1X1")) c->fuse_finish1x1 = e[0] != '0';
-    if (const char* e = getenv("FV_PERSIST_COOP")) c->persist_plain_launch = e[0] == '0';
-    if (const char* e = getenv("FV_PERSIST_SPIN")) c->persist_spin_limit = atoll(e);
-    if (const char* e = getenv("FV_PERSIST_TEST_STALL")) c->persist_test_stall = atoi(e);
-    if (const char* e = getenv("FV_INFER_PERSIST")) c->infer_persist = e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
     c->stream = (hipStream_t)stream;
     // The side stream carries the weight-gradient kernels of the backward overlap at the LOWEST stream priority:
     // the dispatcher then serves the data-gradient / BN-backward chain (the critical path) first and the weight

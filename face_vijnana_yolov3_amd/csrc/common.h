@@ -38,21 +38,6 @@ struct fv_ctx {
     bool wgrad_fused_taps = true;   // fv_set_wgrad_fused_taps: wgrad9_mfma.hip for the 32 -> 64 channel 3x3 layers
     bool conv_halo = true;      // fv_set_conv_halo: conv9_mfma.hip (training forward) and dgrad9s2_mfma.hip (stride-2 data-gradient) for the 32 -> 64 channel 3x3 layers
     bool conv0_direct = true;    // fv_set_conv0_direct: vector-FMA first layer (conv0_direct.hip) instead of the gather kernel
-    // one-launch small-M inference forward (infer_persist.hip; fv_set_infer_persist): 0 off, 1 on, 2 on with the per-layer path's
-    // K-split plan (bit-identical to it)
-    bool fuse_finish1x1 = false;          // fv_set_fuse_finish1x1: per-layer small-M path: split-K finish + following 1x1 layer in one launch (measured at parity: off)
-    int infer_persist = 0;                // (measured at parity with the per-layer launches, DESIGN 10: opt-in)
-    int persist_grid = 0;                 // workgroups of the cooperative launch; 0: two per CU, checked against the occupancy query
-    void* persist_table = nullptr;        // device copy of the phase table (ctx-owned: nothing else may write it) and what it was built for
-    int persist_key[4] = {0, 0, 0, 0};    // batch, image_size, grid, mode
-    int persist_nphase = 0, persist_tiles = 0;
-    double persist_flops = 0.0;
-    unsigned* persist_err_host = nullptr; // pinned host word: a workgroup that abandons a wait stores its code here
-    unsigned long long* persist_trace = nullptr;   // optional per-phase wall-clock stamps of workgroup 0 (fv_infer_persist_trace)
-    bool persist_trace_on = false;
-    long long persist_spin_limit = 0;     // FV_PERSIST_SPIN: polls before a device-side wait gives up (0 = default)
-    bool persist_plain_launch = true;     // plain launch + the library's own occupancy check; false (fv_set_infer_persist_cooperative, FV_PERSIST_COOP=1): hipLaunchCooperativeKernel
-    int persist_test_stall = -1;          // FV_PERSIST_TEST_STALL: test hook, a workgroup that never reaches the third barrier
     ~fv_ctx();
 };
 

@@ -34,12 +34,6 @@ int fv_ew_pad_rows(fv_ctx* ctx, const float* src, float* dst, int N, int K, int 
 int fv_ew_slice_cols(fv_ctx* ctx, const float* src, float* dst, long long rows, int C, int Cpad);
 int fv_ew_splitk_finish(fv_ctx* ctx, const float* slabs, int ksplit, long long stride, const float* scale, const float* shift,
                         const float* skip, float* out, long long n, int C, float leaky, int do_leaky);
-// finish_conv1x1.hip: split-K finish of a layer fused with the 1x1 layer that follows it (small-M inference; bit-identical to
-// fv_ew_splitk_finish + the narrow-tile conv)
-bool fv_ew_finish_conv1x1_ok(int C1, int C2, long long rows);
-int fv_ew_finish_conv1x1(fv_ctx* ctx, const float* slabs, int ks, long long sstride, const float* scale1, const float* shift1,
-                         const float* skip1, float* out1, const float* w2, const float* scale2, const float* shift2, float* out2,
-                         int M, int C1, int C2, float leaky);
 int fv_ew_bn_fold_all(fv_ctx* ctx, const float* params, const float* state, int nlayers, const int* ch_begin, const long long* gamma_off,
                       const long long* beta_off, const long long* mean_off, const long long* var_off, float eps, int total,
                       float* scale, float* shift);

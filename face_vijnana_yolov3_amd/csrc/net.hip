@@ -8,7 +8,6 @@
 #include "conv.h"
 #include "elementwise.h"
 #include "ops.h"
-#include "infer_persist.h"
 
 namespace {
 
@@ -75,7 +74,6 @@ struct Plan {
                                           // backward d-beta/d-gamma (one contiguous range over all layers)
     size_t slots_bytes;
     float *w0p, *yhat, *dyp, *G[4], *loss, *slab, *tail, *mse_part, *head_slab;
-    float* pslab; unsigned* psync; size_t pslab_floats; int psync_words;   // one-launch small-M forward (infer_persist.hip)
     int head_ks;
     size_t tail_floats;
     size_t bytes;
@@ -92,65 +90,6 @@ struct TailLend {
     ~TailLend() { ctx->tail_slab = prev; ctx->tail_slab_floats = prev_floats; }
 };
 
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// One-launch small-M inference forward (infer_persist.hip): layers PERSIST_FIRST .. 51 and the head.  Eligible when the first of
-// those layers has at most PERSIST_MAX_ROWS output pixels (batch 1 at 416 x 416: 52 x 52 = 2704) -- the regime in which the
-// per-layer path K-splits every layer and a forward is ~85 dependent launches.
-constexpr int PERSIST_FIRST = 9;           // conv_12: the first layer at S/8 (all later layers have >= 128 output channels)
-constexpr int PERSIST_MAX_ROWS = 3072;
-constexpr int PERSIST_MAX_GRID = 512;
-
-bool persist_eligible(int B, int S) {
-    const auto& d = net().L[PERSIST_FIRST];
-    return (long long)B * (S / d.out_div) * (S / d.out_div) <= PERSIST_MAX_ROWS;
-}
-
-// K-split of one layer for the persistent grid: `mode` 2 = the per-layer path's plan (fv_conv_choose_ksplit; the 1x1 layers that
-// path runs on narrow unsplit tiles stay unsplit), so that every output element sees the same summation order; mode 1 = as many
-// slices as there are workgroups to take them (items <= grid).
-void persist_split(int mode, int grid, int M, int N, int ksteps, int tiles, int* ks, int* per) {
-    int k;
-    if (mode == 2) k = fv_conv_choose_ksplit(M, N, ksteps);
-    else {
-        k = grid / tiles;
-        if (k < 1) k = 1;
-        if (k > ksteps) k = ksteps;
-    }
-    if ((N & 3) && k < 2) k = 2;                      // rows that are not 16-byte aligned are stored by the reduce pass only
-    *per = (ksteps + k - 1) / k;
-    *ks = (ksteps + *per - 1) / *per;                 // no empty slice
-}
-
-struct PersistPlan {
-    std::vector<FvPersistPhase> ph;
-    int total_tiles = 0;
-    long long slab_floats = 0;
-    double flops = 0.0;
-};
-
-// Buffer offsets (floats from the workspace base) are filled in by the caller; this computes the tiling of every phase.
-PersistPlan persist_tiling(int B, int S, int mode, int grid) {
-    const Net& N = net();
-    PersistPlan pp;
-    for (int l = PERSIST_FIRST; l < (int)N.L.size(); ++l) {
-        const auto& d = N.L[l];
-        FvPersistPhase P{};
-        P.B = B; P.H = P.W = S / d.in_div; P.Cin = d.cin; P.Cout = d.cout; P.ksize = d.ksize; P.stride = d.stride;
-        P.Ho = P.Wo = S / d.out_div; P.M = B * P.Ho * P.Wo;
-        P.nt = (d.cout + 127) / 128; P.tiles = ((P.M + 127) / 128) * P.nt;
-        const int ksteps = d.ksize * d.ksize * d.cin / 32;
-        persist_split(mode, grid, P.M, d.cout, ksteps, P.tiles, &P.ksplit, &P.per);
-        P.items = P.tiles * P.ksplit;
-        P.cnt_off = pp.total_tiles;
-        pp.total_tiles += P.tiles;
-        if (P.ksplit > 1 && (long long)P.items * 128 * 128 > pp.slab_floats) pp.slab_floats = (long long)P.items * 128 * 128;
-        P.leaky_on = d.has_bn ? 1 : 0; P.leaky = LEAKY;
-        pp.flops += 2.0 * P.M * d.cout * (double)(d.ksize * d.ksize * d.cin);
-        pp.ph.push_back(P);
-    }
-    return pp;
-}
 
 // Carve the workspace (base == NULL: size query only).
 Plan make_plan(void* base, int B, int S, bool training) {
@@ -225,18 +164,6 @@ Plan make_plan(void* base, int B, int S, bool training) {
             if (ks > 1 && ks * rows * d.cout > max_slab) max_slab = ks * rows * d.cout;
         }
         p.slab = max_slab ? c.take(max_slab) : nullptr;
-        if (persist_eligible(B, S)) {        // slabs + sync block of the one-launch forward, sized for either plan
-            long long sf = 0; int tiles = 0;
-            for (int mode = 1; mode <= 2; ++mode) {
-                PersistPlan pp = persist_tiling(B, S, mode, PERSIST_MAX_GRID);
-                if (pp.slab_floats > sf) sf = pp.slab_floats;
-                tiles = pp.total_tiles;
-            }
-            p.pslab_floats = (size_t)sf;
-            p.pslab = c.take((size_t)sf);
-            p.psync_words = fv_persist_sync_words(tiles);
-            p.psync = (unsigned*)c.take((size_t)p.psync_words);
-        }
     }
     {   // tail-split scratch: largest need over the forward and (training) stride-1 data-gradient launches
         long long need = 0;
@@ -299,80 +226,6 @@ int fv_train_workspace_tensor(int batch, int image_size, int layer, int which, s
     return FV_OK;
 }
 
-constexpr int FV_PERSIST_FALLBACK = 1000;
-
-// Layers PERSIST_FIRST .. 51 and the head as one cooperative launch.  `cur` (= p.G[icur]) is the output of layer PERSIST_FIRST - 1.
-static int persist_forward(fv_ctx* ctx, const Plan& p, const float* params, float* ws, int batch, int S, const float* cur, int icur, float* y) {
-    const Net& N = net();
-    const int nb = p.nl - 1;
-    const int mode = ctx->infer_persist;
-    int grid = ctx->persist_grid;
-    if (grid == 0) {
-        int per_cu = 0, cus = 0;
-        if (int rc = fv_persist_max_grid(ctx, &per_cu, &cus)) return rc;
-        // one workgroup per CU: measured 1.03 ms in-kernel against 1.11 with two per CU (the second workgroup buys a faster K step,
-        // 1.9 against 2.25 us, and pays for it with twice the arrivals and pollers at every wait and a finer K split)
-        grid = per_cu >= 1 ? cus : 0;
-        if (grid > PERSIST_MAX_GRID) grid = PERSIST_MAX_GRID;
-        grid &= ~7;
-    }
-    if (grid < 8 || grid > PERSIST_MAX_GRID) return FV_PERSIST_FALLBACK;
-    if (!ctx->persist_err_host) {
-        FV_HIP(ctx, hipHostMalloc((void**)&ctx->persist_err_host, 64, hipHostMallocMapped));
-        *ctx->persist_err_host = 0;
-    }
-    const int key[4] = {batch, S, grid, mode};
-    if (!ctx->persist_table || memcmp(key, ctx->persist_key, sizeof key) != 0) {
-        PersistPlan pp = persist_tiling(batch, S, mode, grid);
-        // the same buffer rotation as the per-layer loop of forward_impl
-        int ic = icur, iskip = -1;
-        for (int l = PERSIST_FIRST; l < p.nl; ++l) {
-            const auto& d = N.L[l];
-            FvPersistPhase& P = pp.ph[l - PERSIST_FIRST];
-            P.x_off = p.G[ic] - ws;
-            P.w_off = d.w_off;
-            if (l == nb) {                    // head: linear, bias from params, into the caller's y
-                P.out_sel = 1; P.out_off = 0; P.skip_off = -1; P.scale_off = -1; P.shift_sel = 1; P.shift_off = d.beta_off;
-                break;
-            }
-            if (d.role == 1) iskip = ic;
-            int iout = 0;
-            while (iout == ic || (iout == iskip && (d.role == 1 || d.role == 2))) ++iout;
-            P.out_sel = 0; P.out_off = p.G[iout] - ws;
-            P.skip_off = d.role == 2 ? p.G[iskip] - ws : -1;
-            P.scale_off = p.scale[l] - ws; P.shift_sel = 0; P.shift_off = p.shift[l] - ws;
-            ic = iout;
-            if (d.role == 2) iskip = -1;
-        }
-        if ((size_t)pp.slab_floats > p.pslab_floats || fv_persist_sync_words(pp.total_tiles) > p.psync_words)
-            return fv_fail(ctx, FV_ERR_WORKSPACE, "forward_infer: one-launch plan needs more scratch than the workspace plan reserved");
-        const size_t bytes = pp.ph.size() * sizeof(FvPersistPhase);
-        if (!ctx->persist_table) FV_HIP(ctx, hipMalloc(&ctx->persist_table, 64 * sizeof(FvPersistPhase)));
-        FV_REQUIRE(ctx, pp.ph.size() <= 64, "forward_infer: phase table overflow");
-        // pageable source: the copy has left the host buffer when the call returns; ordered on the stream before the launch
-        FV_HIP(ctx, hipMemcpyAsync(ctx->persist_table, pp.ph.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-        memcpy(ctx->persist_key, key, sizeof key);
-        ctx->persist_nphase = (int)pp.ph.size(); ctx->persist_tiles = pp.total_tiles; ctx->persist_flops = pp.flops;
-    }
-    if (ctx->persist_trace_on && !ctx->persist_trace) FV_HIP(ctx, hipMalloc((void**)&ctx->persist_trace, 256 * sizeof(unsigned long long)));
-    FvPersistArgs a{};
-    a.table = (const FvPersistPhase*)ctx->persist_table; a.nphase = ctx->persist_nphase;
-    a.ws = ws; a.params = params; a.y_ext = y;
-    a.slab_off = p.pslab - ws;
-    a.sync = p.psync; a.err_host = ctx->persist_err_host;
-    a.trace = ctx->persist_trace_on ? ctx->persist_trace : nullptr;
-    a.alg_flops = ctx->persist_flops;
-    a.spin_limit = (unsigned)ctx->persist_spin_limit; a.stall_wg = ctx->persist_test_stall;
-    FV_HIP(ctx, hipMemsetAsync(p.psync, 0, (size_t)fv_persist_sync_words(ctx->persist_tiles) * sizeof(unsigned), ctx->stream));
-    const int rc = fv_persist_launch(ctx, a, grid);
-    if (rc == FV_ERR_HIP) {
-        // hipErrorCooperativeLaunchTooLarge and friends: nothing was enqueued; the caller takes the per-layer path
-        (void)hipGetLastError();
-        return FV_PERSIST_FALLBACK;
-    }
-    return rc;
-}
-
 // inference forward: the 52 base layers (the last one into `feat` when given), then the head into `y` when given
 static int forward_impl(fv_ctx* ctx, const float* params, const float* bn_state, const float* x, int batch, int image_size,
                         void* workspace, size_t workspace_bytes, float* feat, float* y) {
@@ -397,22 +250,9 @@ static int forward_impl(fv_ctx* ctx, const float* params, const float* bn_state,
     const float* cur = x;
     int icur = -1, iskip = -1;
     const float* skip = nullptr;
-    // One cooperative launch for layers PERSIST_FIRST .. head when the forward is in the small-M regime (infer_persist.hip)
-    bool use_persist = ctx->infer_persist != 0 && y && !feat && p.pslab && p.psync;
-    if (ctx->persist_err_host && *ctx->persist_err_host) {       // whatever path this call takes: an earlier launch gave up a wait
-        const unsigned code = *ctx->persist_err_host;
-        *ctx->persist_err_host = 0;
-        return fv_fail(ctx, FV_ERR_HIP, "forward_infer: an earlier one-launch forward abandoned a wait (code %u: %s); its output is invalid",
-                       code, code & FV_PERSIST_ERR_BARRIER ? "grid barrier" : "tile counter");
-    }
     for (int l = 0; l < nb; ++l) {
         const auto& d = N.L[l];
         const int H = image_size / d.in_div;
-        if (use_persist && l == PERSIST_FIRST) {
-            const int rc = persist_forward(ctx, p, params, (float*)workspace, batch, image_size, cur, icur, y);
-            if (rc != FV_PERSIST_FALLBACK) return rc;
-            use_persist = false;               // the runtime refused the cooperative launch: per-layer path
-        }
         if (d.role == 1) { skip = cur; iskip = icur; }
         int iout = 0;
         while (iout == icur || (iout == iskip && (d.role == 1 || d.role == 2))) ++iout;
@@ -424,25 +264,6 @@ static int forward_impl(fv_ctx* ctx, const float* params, const float* bn_state,
             // small M (batch-1 latency): K-split partial slabs, summed in fixed order by the finish kernel
             if (int rc = fv_op_conv_forward(ctx, cur, w, batch, H, H, d.cin, d.cout, d.ksize, d.stride, 0, nullptr, nullptr, 0.f,
                                             nullptr, p.slab, nullptr, nullptr, ks)) return rc;
-            // ... fused with the 1x1 layer of the next residual block where that is a narrow unsplit launch today (52x52 and 26x26 at
-            // batch 1): one launch instead of finish + conv, bit-identical (finish_conv1x1.hip)
-            const bool fuse = ctx->fuse_finish1x1 && l + 1 < nb && N.L[l + 1].ksize == 1 && N.L[l + 1].role == 1 &&
-                              fv_ew_finish_conv1x1_ok(d.cout, N.L[l + 1].cout, rows) &&
-                              fv_conv_choose_ksplit((int)rows, N.L[l + 1].cout, N.L[l + 1].cin / 32) == 1 && !(feat && l + 1 == nb - 1);
-            if (fuse) {
-                const auto& d1 = N.L[l + 1];
-                int iout1 = 0;
-                // layer l+1 opens a block: its input (= out) is the block's skip tensor.  Its output must alias neither `out` nor -- when
-                // layer l closes a block (role 2) -- the skip tensor this same launch still reads in other workgroups
-                while (iout1 == iout || (d.role == 2 && iout1 == iskip)) ++iout1;
-                if (int rc = fv_ew_finish_conv1x1(ctx, p.slab, ks, rows * d.cout, p.scale[l], p.shift[l], d.role == 2 ? skip : nullptr, out,
-                                                  params + d1.w_off, p.scale[l + 1], p.shift[l + 1], p.G[iout1], (int)rows, d.cout, d1.cout,
-                                                  LEAKY)) return rc;
-                skip = out; iskip = iout;
-                cur = p.G[iout1]; icur = iout1;
-                ++l;
-                continue;
-            }
             if (int rc = fv_ew_splitk_finish(ctx, p.slab, ks, rows * d.cout, p.scale[l], p.shift[l], d.role == 2 ? skip : nullptr,
                                              out, rows * d.cout, d.cout, LEAKY, 1)) return rc;
         } else {
@@ -466,34 +287,6 @@ static int forward_impl(fv_ctx* ctx, const float* params, const float* bn_state,
     }
     return fv_op_conv_forward(ctx, cur, params + h.w_off, batch, G, G, h.cin, h.cout, 3, 1, FV_EPI_AFFINE, nullptr,
                               params + h.beta_off, 0.f, nullptr, y, nullptr, nullptr);
-}
-
-int fv_infer_persist_status(fv_ctx* ctx) {
-    if (!ctx) return FV_ERR_INVALID;
-    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->persist_err_host && *ctx->persist_err_host) {
-        const unsigned code = *ctx->persist_err_host;
-        *ctx->persist_err_host = 0;
-        return fv_fail(ctx, FV_ERR_HIP, "one-launch forward abandoned a wait (code %u)", code);
-    }
-    return FV_OK;
-}
-
-int fv_infer_persist_trace(fv_ctx* ctx, int on, double* us, int max_stamps, int* n_out) {
-    if (!ctx) return FV_ERR_INVALID;
-    if (us && n_out) {          // read the stamps of the last launch: [3 * nphase + 1] microseconds since its first stamp
-        *n_out = 0;
-        if (ctx->persist_trace && ctx->persist_nphase > 0) {
-            FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            const int n = 3 * ctx->persist_nphase + 1;
-            std::vector<unsigned long long> t(n);
-            FV_HIP(ctx, hipMemcpy(t.data(), ctx->persist_trace, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            for (int i = 0; i < n && i < max_stamps; ++i) us[i] = (double)(t[i] - t[0]) * 0.01;     // wall_clock64: 100 MHz
-            *n_out = n < max_stamps ? n : max_stamps;
-        }
-    }
-    ctx->persist_trace_on = on != 0;
-    return FV_OK;
 }
 
 int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, const float* x, int batch, int image_size,

@@ -89,30 +89,6 @@ int fv_set_bn_zero_debias_step(fv_ctx* ctx, long long step);
 /* First layer (3 -> 32 channels, K = 27, HBM-bound): 1 (default) a direct vector-FMA kernel with an LDS halo tile
  * whenever W % 32 == 0 and H % 8 == 0; 0 the matrix-core gather kernel.  Bit-identical outputs (same fmaf chain). */
 int fv_set_conv0_direct(fv_ctx* ctx, int on);
-/* Small-M inference (batch 1 at 416 x 416: what `self.model.predict(image)` of detect() is, fd.py:899): layers 9 .. 51 and the head of
- * fv_forward_infer run as ONE launch of persistent, co-resident workgroups with bounded device-side layer barriers instead of ~75
- * dependent launches.  mode 0 (default): off (per-layer launches); 1: on; 2: on with the per-layer path's K-split plan -- bit-identical
- * to mode 0.  grid: workgroups of the launch (multiple of 8; 0 = one per CU, checked by the runtime against the occupancy).  Measured on MI355X
- * at 416 x 416: 1.27 ms per image with mode 1 against 1.26 ms for the per-layer launches (DESIGN 10 has the per-phase breakdown) -- the
- * device-side barriers cost what the launch boundaries they replace cost, hence opt-in.  A
- * launch the runtime refuses falls back to mode 0; a wait abandoned on the device is reported by the next fv_forward_infer /
- * fv_infer_persist_status (synchronises) as FV_ERR_HIP. */
-int fv_set_infer_persist(fv_ctx* ctx, int mode, int grid);
-/* How the one-launch forward is started.  0 (default): a plain launch on the context's stream after the library has checked the grid
- * against hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs itself -- the same residency (plain, cooperative and graph launches place a
- * grid alike) on the stream's own hardware queue.  1: hipLaunchCooperativeKernel -- the runtime makes that check; the launch goes through
- * the device's cooperative queue and is ordered against every other queue of the process (measured: 2.1 instead of 1.3 ms per forward
- * once an RCCL communicator has existed in the process).  Either way every device-side wait is bounded. */
-int fv_set_infer_persist_cooperative(fv_ctx* ctx, int on);
-/* Per-layer small-M path: 1 (default) the split-K finish of a 3x3 layer and the 1x1 layer that opens the next residual block run as
- * ONE launch (a workgroup sums the slabs of 32 pixels, applies BN / LeakyReLU / skip, stores that activation and multiplies it with
- * the 1x1 kernel on the matrix cores); 0 (default): finish kernel + conv launch.  Bit-identical results; measured at parity (16 launches
- * fewer per image, but 32 or 16 pixels per workgroup leave the slab sums to 85 - 340 workgroups where the finish kernel uses every CU). */
-int fv_set_fuse_finish1x1(fv_ctx* ctx, int on);
-int fv_infer_persist_status(fv_ctx* ctx);
-/* Per-phase wall-clock stamps of workgroup 0 of the next one-launch forwards (on != 0); with us != NULL first returns those of the last
- * launch: for every phase its start, the end of its tile loop, the end of its slab reduction, then the end of the launch; microseconds. */
-int fv_infer_persist_trace(fv_ctx* ctx, int on, double* us, int max_stamps, int* n_out);
 /* The per-operator conv entry points (fv_conv2d_forward / fv_conv2d_dgrad) have no workspace
  * argument; a caller that wants the tail split there lends device scratch here (NULL, 0 = none;
  * 64 MiB covers every Darknet-53 shape at batch 40).  The buffer must stay valid until the calls that

@@ -1,0 +1,86 @@
+"""BASELINE config 5 at its per-GPU size (image_size 608, batch 16: grid 19, 5 776 rows in the 19x19 layers = 46 M tiles whose
+128-wide launches take the tail-split plans; 92 416 rows at 76x76) where the CPU oracle cannot run in seconds: the
+size-independent properties tests/test_fullsize_gpu.py checks at 40 x 416^2, on the plans this size really runs.
+(One image at 608 is compared with the oracle in tests/test_net_gpu.py::test_config5_608_grid19.)"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+B, S = 16, 608
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from face_vijnana_yolov3_amd.engine import Engine
+    e = Engine(0)
+    e.init_synthetic(seed=7)
+    return e
+
+
+@pytest.fixture(scope='module')
+def batch():
+    from face_vijnana_yolov3_amd import data
+    g = torch.Generator().manual_seed(608)
+    x = torch.rand((B, S, S, 3), generator=g).cuda()
+    y = torch.from_numpy(data.synth_gt_batch(B, S, seed=608)).cuda()
+    return x, y
+
+
+def test_608_inference_is_per_image_and_deterministic(eng, batch):
+    """Inference-mode BN is per sample: the batch in two uneven parts (other tile counts, other tail plans, the K-split path for
+    the small part's 19x19 layers) reproduces the full-batch result to fp32 rounding; repeated calls are bit-identical; the
+    tail split on / off changes only the summation order of the tail tiles."""
+    x, _ = batch
+    y = eng.predict_device(x).clone()
+    assert torch.equal(y, eng.predict_device(x))
+    assert tuple(y.shape) == (B, 19, 19, 6) and bool(torch.isfinite(y).all())
+    ys = torch.cat([eng.predict_device(x[:5].contiguous()).clone(), eng.predict_device(x[5:].contiguous()).clone()])
+    assert (ys - y).abs().max().item() <= 2e-5 * y.abs().max().item()
+    eng.ctx.set_tail_split(False)
+    try:
+        yn = eng.predict_device(x).clone()
+    finally:
+        eng.ctx.set_tail_split(True)
+    assert (yn - y).abs().max().item() <= 2e-5 * y.abs().max().item()
+
+
+def test_608_train_step_batch_permutation_invariance(eng, batch):
+    """Batch statistics, the loss and every gradient are symmetric in the batch order (bounds as at 416: the head tight, the base
+    layers at the measured conditioning of the randomly initialised network)."""
+    x, y = batch
+    p0, s0 = eng.params.clone(), eng.state.clone()
+    eng.grads = eng.m = eng.v = None
+    l1 = eng.forward_backward(x, y).clone(); g1 = eng.grads.clone(); st1 = eng.state.clone()
+    eng.set_params(p0, s0)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).cuda()
+    l2 = eng.forward_backward(x[perm].contiguous(), y[perm].contiguous()).clone(); g2 = eng.grads.clone()
+    torch.cuda.synchronize()
+    assert abs(l1.item() - l2.item()) <= 2e-6 * abs(l1.item())
+    torch.testing.assert_close(eng.state, st1, rtol=1e-5, atol=1e-7)
+    nl = len(eng.layers)
+    for li, d in enumerate(eng.layers):
+        n = d['cout'] * d['ksize'] ** 2 * d['cin']
+        a, b = g1[d['w_off']:d['w_off'] + n], g2[d['w_off']:d['w_off'] + n]
+        tol = 1e-4 if li == nl - 1 else 6e-2
+        assert (a - b).abs().max().item() <= tol * a.abs().max().item() + 1e-12, (d['darknet_index'], li)
+    eng.set_params(p0, s0)
+
+
+def test_608_gradient_matches_directional_derivative(eng, batch):
+    """Forward and backward kernels agree at this size: along d = g / |g|, (L(p + e d) - L(p - e d)) / 2e == |g|."""
+    x, y = batch
+    p0, s0 = eng.params.clone(), eng.state.clone()
+    eng.grads = eng.m = eng.v = None
+    eng.forward_backward(x, y)
+    g = eng.grads.clone().double()
+    gn = g.norm().item()
+    d = (g / gn).float()
+    ratios = []
+    for e in (2e-3, 5e-3):
+        eng.set_params(p0 + e * d, s0); lp = eng.forward_backward(x, y).item()
+        eng.set_params(p0 - e * d, s0); lm = eng.forward_backward(x, y).item()
+        ratios.append((lp - lm) / (2 * e) / gn)
+    eng.set_params(p0, s0)
+    eng.grads = eng.m = eng.v = None
+    assert min(abs(r - 1.0) for r in ratios) < 0.05, ratios
