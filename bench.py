@@ -11,7 +11,7 @@ are already resident in HBM.  Rank 0 prints ONE JSON line.
 
 `roofline`: the dominant kernel is the 128x128-tile fp32-MFMA implicit-GEMM conv
 (conv_kernel<128,2,4,false>, 8 waves per workgroup: forward and data-gradient of every layer with >= 128
-output channels; conv_kernel<128,2,2,false> under fv_set_conv_waves8(0)).  achieved = algorithmic FLOPs of its launches / their HIP-event-timed duration, taken in
+output channels; conv_kernel<128,2,2,false> under fv_set_option("conv_waves8", 0)).  achieved = algorithmic FLOPs of its launches / their HIP-event-timed duration, taken in
 instrumented steps right after the timed region (the timed steps themselves run un-instrumented).
 peak = 157.3 TFLOP/s, the dense fp32 MFMA rate of MI355X (MI355X_MICROARCH.md).
 `cpu_baseline`: the torch-CPU oracle restatement of the same step (kind "port"; the Keras/TF
@@ -636,7 +636,7 @@ def main():
         multi = rccl_world1_rehearsal(eng, x, y)     # right after the timed region: same clocks, same allocator state
 
     # instrumented steps for the roofline of the dominant kernel (HIP events on the launch stream).
-    # They run with fv_set_overlap(0): under the backward overlap two MFMA kernels time-share the
+    # They run with fv_set_option("overlap", 0): under the backward overlap two MFMA kernels time-share the
     # chip and a launch's elapsed time is no longer that kernel's own rate (the timed region above
     # keeps the overlap; `roofline_overlapped` repeats the measurement with it on).  EVERY rank runs
     # these steps (they contain the gradient collectives); only rank 0 records events.
@@ -703,7 +703,7 @@ def main():
                             frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
                             kernel=dom_name,
                             algorithmic_bytes_per_launch=round(dom['bytes'] / dom['launches']),
-                            mode='exclusive: instrumented steps run with fv_set_overlap(0)',
+                            mode='exclusive: instrumented steps run with fv_set_option("overlap", 0)',
                             launches_per_step=dom['launches'] // max(args.profile_steps, 1),
                             avg_launch_ms=round(dom['ms'] / dom['launches'], 4),
                             gflop_per_launch=round(dom['flops'] / dom['launches'] / 1e9, 3))

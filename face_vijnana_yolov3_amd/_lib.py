@@ -61,15 +61,11 @@ BUCKET_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 def _declare(L):
     i32, i64, f32, f64, vp, sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, c_void_p, ctypes.c_size_t
     sig = {
-        'fv_set_overlap': (i32, [vp, i32]),
-        'fv_set_tail_split': (i32, [vp, i32]),
+        'fv_set_option': (i32, [vp, c_char_p, ctypes.c_longlong]),
+        'fv_get_option': (i32, [vp, c_char_p, ctypes.POINTER(ctypes.c_longlong)]),
         'fv_set_bucket_on_side': (i32, [vp, i32]),
         'fv_side_stream': (vp, [vp]),
         'fv_set_conv_scratch': (i32, [vp, vp, sz]),
-        'fv_set_conv0_direct': (i32, [vp, i32]),
-        'fv_set_conv_waves8': (i32, [vp, i32]),
-        'fv_set_conv_halo': (i32, [vp, i32]),
-        'fv_set_wgrad_fused_taps': (i32, [vp, i32]),
         'fv_set_bn_zero_debias_step': (i32, [vp, ctypes.c_longlong]),
         'fv_profile_enable': (i32, [vp, i32]),
         'fv_profile_collect': (i32, [vp, ctypes.POINTER(ProfileRec), i32, ctypes.POINTER(i32)]),
@@ -136,7 +132,7 @@ class Context:
         torch.cuda.set_device(self.device)
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.overlap = True            # fv_set_overlap's state (the library's default)
+        self.overlap = True            # option 'overlap' (kept (the library's default)
         self._h = c_void_p()
         rc = lib().fv_create(self.device, c_void_p(stream), ctypes.byref(self._h))
         if rc != 0:
@@ -153,8 +149,18 @@ class Context:
     def set_stream(self, stream_ptr):
         self.check(lib().fv_set_stream(self._h, c_void_p(stream_ptr)), 'fv_set_stream')
 
+    def set_option(self, key, value):
+        """fv_set_option: a tuning switch of include/fv_hotpath.h ('overlap', 'tail_split', 'conv_waves8', 'conv1x1_persist',
+        'conv_halo', 'conv0_direct', 'wgrad_fused_taps')."""
+        self.check(lib().fv_set_option(self._h, key.encode(), int(value)), 'fv_set_option(%s)' % key)
+
+    def get_option(self, key):
+        v = ctypes.c_longlong(0)
+        self.check(lib().fv_get_option(self._h, key.encode(), ctypes.byref(v)), 'fv_get_option(%s)' % key)
+        return int(v.value)
+
     def set_overlap(self, on):
-        self.check(lib().fv_set_overlap(self._h, 1 if on else 0), 'fv_set_overlap')
+        self.set_option('overlap', 1 if on else 0)
         self.overlap = bool(on)
 
     def set_bucket_on_side(self, on):
@@ -169,22 +175,22 @@ class Context:
         self.check(lib().fv_scale(self._h, ptr(tensor), tensor.numel(), float(alpha)), 'fv_scale')
 
     def set_tail_split(self, on):
-        self.check(lib().fv_set_tail_split(self._h, 1 if on else 0), 'fv_set_tail_split')
+        self.set_option('tail_split', 1 if on else 0)
 
     def set_bn_zero_debias_step(self, step):
         self.check(lib().fv_set_bn_zero_debias_step(self._h, int(step)), 'fv_set_bn_zero_debias_step')
 
     def set_wgrad_fused_taps(self, on):
-        self.check(lib().fv_set_wgrad_fused_taps(self._h, 1 if on else 0), 'fv_set_wgrad_fused_taps')
+        self.set_option('wgrad_fused_taps', 1 if on else 0)
 
     def set_conv_halo(self, on):
-        self.check(lib().fv_set_conv_halo(self._h, 1 if on else 0), 'fv_set_conv_halo')
+        self.set_option('conv_halo', 1 if on else 0)
 
     def set_conv_waves8(self, on):
-        self.check(lib().fv_set_conv_waves8(self._h, 1 if on else 0), 'fv_set_conv_waves8')
+        self.set_option('conv_waves8', 1 if on else 0)
 
     def set_conv0_direct(self, on):
-        self.check(lib().fv_set_conv0_direct(self._h, 1 if on else 0), 'fv_set_conv0_direct')
+        self.set_option('conv0_direct', 1 if on else 0)
 
     def set_conv_scratch(self, tensor):
         """Lend device scratch (a torch tensor, kept alive here) to the per-operator conv calls."""

@@ -58,11 +58,41 @@ FvProfScope::~FvProfScope() {
 
 extern "C" {
 
-int fv_abi_version(void) { return 2; }   // 2: fv_train_step / fv_yolov3_train_step take loss_weight; fv_scale
+int fv_abi_version(void) { return 3; }   // 3: fv_set_option / fv_get_option replace the per-switch setters; the opt-in batch-1 variants are gone
 
-int fv_set_overlap(fv_ctx* ctx, int on) {
+// Tuning options (include/fv_hotpath.h, "tuning"): every switch is a bool member of the context; all default to on.
+namespace {
+struct FvOption { const char* key; bool fv_ctx::*member; };
+const FvOption kOptions[] = {
+    {"overlap", &fv_ctx::overlap},
+    {"tail_split", &fv_ctx::tail_split},
+    {"conv_waves8", &fv_ctx::conv_waves8},
+    {"conv1x1_persist", &fv_ctx::conv1x1_persist},
+    {"conv_halo", &fv_ctx::conv_halo},
+    {"conv0_direct", &fv_ctx::conv0_direct},
+    {"wgrad_fused_taps", &fv_ctx::wgrad_fused_taps},
+};
+const FvOption* find_option(const char* key) {
+    if (!key) return nullptr;
+    for (const auto& o : kOptions)
+        if (std::string(o.key) == key) return &o;
+    return nullptr;
+}
+}  // namespace
+
+int fv_set_option(fv_ctx* ctx, const char* key, long long value) {
     if (!ctx) return FV_ERR_INVALID;
-    ctx->overlap = on != 0;
+    const FvOption* o = find_option(key);
+    if (!o) return fv_fail(ctx, FV_ERR_INVALID, "fv_set_option: unknown option '%s'", key ? key : "(null)");
+    ctx->*(o->member) = value != 0;
+    return FV_OK;
+}
+
+int fv_get_option(fv_ctx* ctx, const char* key, long long* value) {
+    if (!ctx || !value) return FV_ERR_INVALID;
+    const FvOption* o = find_option(key);
+    if (!o) return fv_fail(ctx, FV_ERR_INVALID, "fv_get_option: unknown option '%s'", key ? key : "(null)");
+    *value = ctx->*(o->member) ? 1 : 0;
     return FV_OK;
 }
 
@@ -74,39 +104,9 @@ int fv_set_bucket_on_side(fv_ctx* ctx, int on) {
 
 void* fv_side_stream(fv_ctx* ctx) { return ctx ? (void*)ctx->side : nullptr; }
 
-int fv_set_tail_split(fv_ctx* ctx, int on) {
-    if (!ctx) return FV_ERR_INVALID;
-    ctx->tail_split = on != 0;
-    return FV_OK;
-}
-
-int fv_set_conv_waves8(fv_ctx* ctx, int on) {
-    if (!ctx) return FV_ERR_INVALID;
-    ctx->conv_waves8 = on != 0;
-    return FV_OK;
-}
-
 int fv_set_bn_zero_debias_step(fv_ctx* ctx, long long step) {
     if (!ctx || step < 0) return FV_ERR_INVALID;
     ctx->bn_ema_step = step;
-    return FV_OK;
-}
-
-int fv_set_wgrad_fused_taps(fv_ctx* ctx, int on) {
-    if (!ctx) return FV_ERR_INVALID;
-    ctx->wgrad_fused_taps = on != 0;
-    return FV_OK;
-}
-
-int fv_set_conv_halo(fv_ctx* ctx, int on) {
-    if (!ctx) return FV_ERR_INVALID;
-    ctx->conv_halo = on != 0;
-    return FV_OK;
-}
-
-int fv_set_conv0_direct(fv_ctx* ctx, int on) {
-    if (!ctx) return FV_ERR_INVALID;
-    ctx->conv0_direct = on != 0;
     return FV_OK;
 }
 
@@ -167,7 +167,20 @@ int fv_create(int device, void* stream, fv_ctx** out) {
                        prop.gcnArchName);
     fv_ctx* c = new fv_ctx();
     c->device = device;
-    if (const char* e = getenv("FV_CONV_WAVES8")) c->conv_waves8 = e[0] != '0';
+    // FV_OPTIONS="key=0,key=1,...": initial values of the tuning options (A/B runs of unmodified programs)
+    if (const char* e = getenv("FV_OPTIONS")) {
+        std::string spec(e);
+        size_t pos = 0;
+        while (pos < spec.size()) {
+            size_t end = spec.find(',', pos);
+            if (end == std::string::npos) end = spec.size();
+            const std::string item = spec.substr(pos, end - pos);
+            const size_t eq = item.find('=');
+            if (eq != std::string::npos)
+                if (const FvOption* o = find_option(item.substr(0, eq).c_str())) c->*(o->member) = item[eq + 1] != '0';
+            pos = end + 1;
+        }
+    }
     c->stream = (hipStream_t)stream;
     // The side stream carries the weight-gradient kernels of the backward overlap at the LOWEST stream priority:
     // the dispatcher then serves the data-gradient / BN-backward chain (the critical path) first and the weight

@@ -23,7 +23,7 @@ struct fv_ctx {
     std::vector<FvProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
     // backward-pass overlap: weight-gradient kernels run on a side stream next to the
-    // data-gradient / BN-backward chain (fv_set_overlap)
+    // data-gradient / BN-backward chain (option "overlap")
     bool overlap = true;
     hipStream_t side = nullptr;
     bool bucket_on_side = false;   // fv_set_bucket_on_side: fv_bucket_fn fires when the range's weight-gradient is in the side stream's queue
@@ -33,11 +33,12 @@ struct fv_ctx {
     float* tail_slab = nullptr;
     long long tail_slab_floats = 0;
     bool tail_split = true;
-    bool conv_waves8 = true;     // 512-thread (8-wave) form of the 128x128 conv kernel (FV_CONV_WAVES8=0: the 4-wave form)
+    bool conv_waves8 = true;     // 512-thread (8-wave) form of the 128x128 conv kernel (option "conv_waves8" = 0: the 4-wave form)
     long long bn_ema_step = 0;   // fv_set_bn_zero_debias_step: 0 plain EMA of the BN moving statistics, t >= 1 Keras 2.2.4's zero-debiased update t
-    bool wgrad_fused_taps = true;   // fv_set_wgrad_fused_taps: wgrad9_mfma.hip for the 32 -> 64 channel 3x3 layers
-    bool conv_halo = true;      // fv_set_conv_halo: conv9_mfma.hip (training forward) and dgrad9s2_mfma.hip (stride-2 data-gradient) for the 32 -> 64 channel 3x3 layers
-    bool conv0_direct = true;    // fv_set_conv0_direct: vector-FMA first layer (conv0_direct.hip) instead of the gather kernel
+    bool wgrad_fused_taps = true;   // option "wgrad_fused_taps": wgrad9_mfma.hip for the 32 -> 64 channel 3x3 layers
+    bool conv_halo = true;      // option "conv_halo": conv9_mfma.hip (training forward) and dgrad9s2_mfma.hip (stride-2 data-gradient) for the 32 -> 64 channel 3x3 layers
+    bool conv1x1_persist = true; // option "conv1x1_persist": conv1x1_mfma.hip for 1x1 launches with more than 512 tiles
+    bool conv0_direct = true;    // option "conv0_direct": vector-FMA first layer (conv0_direct.hip) instead of the gather kernel
     ~fv_ctx();
 };
 

@@ -71,6 +71,9 @@ int fv_conv9_fwd_launch(fv_ctx* ctx, const FvConvArgs& a);
 // dgrad9s2_mfma.hip: data-gradient (+ fused BN-backward reduction) of the stride-2 32 -> 64 channel 3x3 layer from a dy halo tile (bit-identical dx)
 bool fv_dgrad9s2_ok(const FvConvArgs& a);
 int fv_dgrad9s2_launch(fv_ctx* ctx, const FvConvArgs& a);
+// conv1x1_mfma.hip: 1x1 stride-1 launches with more tiles than resident workgroup slots as a persistent GEMM (bit-identical)
+bool fv_conv1x1_persist_ok(const FvConvArgs& a);
+int fv_conv1x1_persist_launch(fv_ctx* ctx, const FvConvArgs& a);
 // conv0_direct.hip: the 3 -> 32 channel first layer as a direct vector-FMA convolution (bit-identical to the gather kernel)
 bool fv_conv0_direct_ok(const FvConvArgs& a);
 int fv_conv0_direct_launch(fv_ctx* ctx, const FvConvArgs& a);

@@ -18,15 +18,9 @@
 //  * XCD-aware bijective remap of blockIdx so tiles that share an A panel land on one L2
 #include <string>
 #include <type_traits>
-#include "conv.h"
+#include "conv_tile.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int BM = 128;
-constexpr int BK = 32;
 
 // Phase stamps of every workgroup (tools/build_variant.sh stamps -DFV_CONV_STAMPS; tools/conv_phases.py): kernel entry, first
 // operand tile staged, K loop done, last store issued -- wall_clock64 (100 MHz, the same clock on every CU) + the hardware id.
@@ -51,88 +45,6 @@ __device__ unsigned long long g_stamps[STAMP_WGS * 5];
 #else
 #define FV_STAMP(k) do {} while (0)
 #endif
-constexpr int LDT = BK + 4;  // padded LDS row (dwords)
-
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    int q = nwg >> 3, r = nwg & 7, x = bid & 7, pos = bid >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + pos;
-}
-
-// Fused BatchNorm-backward reduction (FV_EPI_BNRED): the tile just produced is the gradient g w.r.t. the
-// OUTPUT of a BN+LeakyReLU layer; with that layer's pre-BN tensor z the epilogue also forms
-// gy = g * leaky'(z*scale+shift) and accumulates the column sums of gy and gy * xhat (d-beta, d-gamma)
-// into that layer's fp64 slots -- the separate reduction pass over (g, z) disappears.
-struct BnRedAcc {
-    float4 sc, sh, mu, is, db, dg;
-    __device__ __forceinline__ void init(const FvConvArgs& a, int n, bool on) {
-        db = make_float4(0.f, 0.f, 0.f, 0.f); dg = db;
-        sc = sh = mu = is = db;
-        if (on) {
-            sc = *reinterpret_cast<const float4*>(a.bn_scale + n); sh = *reinterpret_cast<const float4*>(a.bn_shift + n);
-            mu = *reinterpret_cast<const float4*>(a.bn_mean + n); is = *reinterpret_cast<const float4*>(a.bn_invstd + n);
-        }
-    }
-    __device__ __forceinline__ void add(const float4& g, const float4& z, float leaky) {
-        float gy;
-        gy = (z.x * sc.x + sh.x) > 0.f ? g.x : g.x * leaky; db.x += gy; dg.x += gy * ((z.x - mu.x) * is.x);
-        gy = (z.y * sc.y + sh.y) > 0.f ? g.y : g.y * leaky; db.y += gy; dg.y += gy * ((z.y - mu.y) * is.y);
-        gy = (z.z * sc.z + sh.z) > 0.f ? g.z : g.z * leaky; db.z += gy; dg.z += gy * ((z.z - mu.z) * is.z);
-        gy = (z.w * sc.w + sh.w) > 0.f ? g.w : g.w * leaky; db.w += gy; dg.w += gy * ((z.w - mu.w) * is.w);
-    }
-};
-// reduce the per-thread sums over the row lanes through LDS (scratch: 2 * RL * BN floats) and add the tile's column sums to
-// slot `row_id % nslot`.  With more than 256 threads the two row lanes that share a wave (lanes l and l ^ 32 hold the same
-// four columns when BN = 128) are combined by a shuffle first, so that the scratch still fits behind the output tile.
-template <int BN, int NTH>
-__device__ __forceinline__ void bnred_flush(const FvConvArgs& a, const BnRedAcc& r, float* scratch, int n0, int row_id) {
-    constexpr int C4 = BN / 4;
-    constexpr bool PAIR = NTH > 256;          // pre-reduce the row lanes that share a wave: one scratch row per wave
-    static_assert(!PAIR || (64 % C4 == 0), "the in-wave pre-reduction needs the column groups to tile a wave");
-    constexpr int RL = PAIR ? NTH / 64 : NTH / C4;
-    const int tid = threadIdx.x, c4 = (tid % C4) * 4;
-    float4 db = r.db, dg = r.dg;
-    int rl = tid / C4;
-    bool writer = true;
-    if constexpr (PAIR) {
-#pragma unroll
-        for (int o = C4; o < 64; o <<= 1) {   // lanes l and l ^ o hold the same four columns
-            db.x += __shfl_xor(db.x, o); db.y += __shfl_xor(db.y, o); db.z += __shfl_xor(db.z, o); db.w += __shfl_xor(db.w, o);
-            dg.x += __shfl_xor(dg.x, o); dg.y += __shfl_xor(dg.y, o); dg.z += __shfl_xor(dg.z, o); dg.w += __shfl_xor(dg.w, o);
-        }
-        writer = (tid & 63) < C4;
-        rl = tid >> 6;
-    }
-    float (*red)[RL][BN] = reinterpret_cast<float (*)[RL][BN]>(scratch);
-    __syncthreads();
-    if (writer) {
-        *reinterpret_cast<float4*>(&red[0][rl][c4]) = db;
-        *reinterpret_cast<float4*>(&red[1][rl][c4]) = dg;
-    }
-    __syncthreads();
-    if (tid < BN && n0 + tid < a.Nout) {
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int w = 0; w < RL; ++w) { s += red[0][w][tid]; q += red[1][w][tid]; }
-        double* sl = a.bn_slots + (size_t)(row_id % a.bn_nslot) * 2 * a.Nout;
-        unsafeAtomicAdd(sl + n0 + tid, (double)s);
-        unsafeAtomicAdd(sl + a.Nout + n0 + tid, (double)q);
-    }
-}
-
-// Column sum / sum of squares of one tile: either its own partial row (deterministic; reduced later by
-// bn_finalize) or added to one of a few fp64 accumulator slots (fp32 partials are exact in fp64; only
-// the order of the fp64 additions varies, far below fp32 resolution) which the consumer kernel sums
-// itself -- that saves the finalize launch between the conv and the normalise pass.
-__device__ __forceinline__ void stat_store(const FvConvArgs& a, int mt, int n, float s, float q) {
-    if (a.stat_slots) {
-        double* sl = a.stat_slots + (size_t)(mt % a.stat_nslot) * 2 * a.Nout;
-        unsafeAtomicAdd(sl + n, (double)s);
-        unsafeAtomicAdd(sl + a.Nout + n, (double)q);
-    } else {
-        a.psum[(size_t)mt * a.Nout + n] = s;
-        a.psq[(size_t)mt * a.Nout + n] = q;
-    }
-}
 
 template <int BN, int WAVES_M, int WAVES_N, bool GATHER>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const FvConvArgs a) {
@@ -504,7 +416,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const F
                 }
             }
         }
-        if (bnred) bnred_flush<BN, NTH>(a, br, smem + BM * BN, n0, mt + cls * (int)(gridDim.x / NT));
+        if (bnred) bnred_flush<BN, NTH>(a, br, smem + BM * BN, n0, mt + cls * (int)(gridDim.x / NT), tid);
         FV_STAMP(3);
         return;
     }
@@ -599,7 +511,7 @@ __global__ __launch_bounds__(1024) void conv_tail_fixup_kernel(const FvConvArgs 
             if (bnred) br.add(v, zv, a.bn_leaky);
         }
     }
-    if (bnred) bnred_flush<BN, NTH>(a, br, &red[0][0][0], n0, mt);
+    if (bnred) bnred_flush<BN, NTH>(a, br, &red[0][0][0], n0, mt, tid);
     if (a.epi & FV_EPI_STATS) {
         // rows outside the problem are zero in every slice, so they add nothing
         *reinterpret_cast<float4*>(&red[0][rl][c4]) = cs;
@@ -763,6 +675,7 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
     for (int c = 0; c < a.nclass; ++c)
         FV_REQUIRE(ctx, a.taps[c].n >= 1 && a.taps[c].n <= 9, "conv: bad tap count");
     if (a.narrow) return launch_cfg<32, 4, 1, false>(ctx, a);
+    if (ctx->conv1x1_persist && fv_conv1x1_persist_ok(a)) return fv_conv1x1_persist_launch(ctx, a);
     // 128-wide tiles: 8 waves (2 x 4, each 64 x 32) put four waves on every SIMD instead of two: the same per-element fmaf
     // chain (bit-identical outputs), 129 against 121 TF on the 52x52 layers
     if (a.Nout > 64) return ctx->conv_waves8 ? launch_cfg<128, 2, 4, false>(ctx, a) : launch_cfg<128, 2, 2, false>(ctx, a);

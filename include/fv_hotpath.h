@@ -42,12 +42,6 @@ int fv_create(int device, void* stream, fv_ctx** out);
 void fv_destroy(fv_ctx* ctx);
 const char* fv_last_error(const fv_ctx* ctx);
 int fv_set_stream(fv_ctx* ctx, void* stream);
-/* fv_train_step runs the weight-gradient kernels on an internal side stream, concurrently with the
- * data-gradient / BN-backward chain on the context's stream (they are independent given dz); all
- * side-stream work is joined back into the context's stream before fv_train_step returns control
- * of a gradient range (fv_bucket_fn) and before it returns.  on = 0 serialises everything on the
- * context's stream (default: on). */
-int fv_set_overlap(fv_ctx* ctx, int on);
 /* Where fv_bucket_fn fires.  Default (0): after the context's stream has been made to wait for the range's weight-gradient --
  * work the callback enqueues on the context's stream sees the finished range.  on = 1 (with the overlap on): as soon as the
  * range's weight-gradient kernels are in the SIDE stream's queue -- the callback must enqueue its work (the all-reduce of the
@@ -55,28 +49,6 @@ int fv_set_overlap(fv_ctx* ctx, int on);
  * between the context's stream and the communication; the side stream is joined before fv_train_step returns. */
 int fv_set_bucket_on_side(fv_ctx* ctx, int on);
 void* fv_side_stream(fv_ctx* ctx);   /* the hipStream_t of the internal side stream */
-/* Tail split of the conv launches inside fv_train_step / fv_forward_infer: when the 128x128 output
- * tiles of a layer do not fill a whole number of rounds of the 512 resident workgroup slots, the
- * tiles of the last partial round are cut into K slices (one workgroup each) whose partial tiles a
- * fix-up kernel sums in fixed slice order before the epilogue.  Deterministic; changes only the
- * fp32 summation order of those tiles (default: on). */
-int fv_set_tail_split(fv_ctx* ctx, int on);
-/* 128-wide conv tiles (forward and data-gradient of every layer with >= 128 output channels): 1 (default) 512-thread
- * workgroups, 8 waves of 64x32 -- four waves per SIMD cover each other's barriers and LDS latency; 0: 256 threads,
- * 4 waves of 64x64.  Same k-ordered fmaf chain per output element: bit-identical results. */
-int fv_set_conv_waves8(fv_ctx* ctx, int on);
-/* Weight-gradients of the early layers: 1 (default) the 3x3 layers with 32 input and 64 output channels (conv_1, conv_3) and the
- * first layer (3 -> 32) stage the x halo and the dy tile of a pixel unit once and multiply all nine taps from it
- * (wgrad9_mfma.hip, wgrad0_mfma.hip), the 1x1 layer with 64 -> 32 channels (conv_2) streams 128-pixel units (wgrad1_mfma.hip);
- * 0 the generic kernels (one workgroup per tap / element-wise gather / 32-pixel chunks).  Same products, different
- * float-atomic summation order. */
-int fv_set_wgrad_fused_taps(fv_ctx* ctx, int on);
-/* Halo-tile kernels for the 3x3 layers with 32 input and 64 output channels (conv_1, conv_3): 1 (default) the training-mode
- * forward (raw z + statistics slots; conv9_mfma.hip) and the stride-2 data-gradient with or without the fused BN-backward
- * reduction (dgrad9s2_mfma.hip) run one workgroup per CU that keeps all weights in LDS and multiplies units of 8x16 pixels
- * from an operand halo tile staged once; 0 the generic tile kernel.  Same k-ordered fmaf chains: z and dx are bit-identical;
- * the statistics / reduction sums are the same sums accumulated in another order (fp64). */
-int fv_set_conv_halo(fv_ctx* ctx, int on);
 /* Update rule of the BatchNormalization moving mean / variance in every training-mode BN launch that follows (reference
  * yd.py:212 `BatchNormalization(epsilon=0.001)`; the update itself is third-party: Keras 2.2.4 `K.moving_average_update` ->
  * TF 1.x `assign_moving_average(..., zero_debias=True)`).  step = 0 (default): plain EMA, moving <- m moving + (1 - m) batch.
@@ -86,9 +58,33 @@ int fv_set_conv_halo(fv_ctx* ctx, int on);
  * fv_yolov3_train_step (which resets it to 0 when it returns) or by the per-operator fv_bn_finalize / fv_bn_act_slots calls that
  * follow; the caller sets t before every training step.  Parity unpinned (neither Keras nor TF is importable here). */
 int fv_set_bn_zero_debias_step(fv_ctx* ctx, long long step);
-/* First layer (3 -> 32 channels, K = 27, HBM-bound): 1 (default) a direct vector-FMA kernel with an LDS halo tile
- * whenever W % 32 == 0 and H % 8 == 0; 0 the matrix-core gather kernel.  Bit-identical outputs (same fmaf chain). */
-int fv_set_conv0_direct(fv_ctx* ctx, int on);
+/* ------------------------------------------------------------------ tuning
+ * Schedule / kernel-selection switches with no counterpart in the reference.  None of them changes WHAT is computed: every
+ * value gives results that are bit-identical or differ only in fp32 summation order (stated per key); all default to 1 (the
+ * fastest measured configuration) and exist for A/B measurements and for the tests that compare the specialised
+ * kernels with the generic ones.  key (value != 0 = on):
+ *   "overlap"           fv_train_step runs the weight-gradient kernels on an internal side stream, concurrently with the
+ *                       data-gradient / BN-backward chain on the context's stream (independent given dz); all side-stream work is
+ *                       joined back before a gradient range is reported (fv_bucket_fn) and before the call returns.  0 serialises
+ *                       everything on the context's stream.
+ *   "tail_split"        when the 128x128 output tiles of a conv launch do not fill whole rounds of the 512 resident workgroup
+ *                       slots, the tiles of the last partial round are cut into K slices whose partial tiles a fix-up kernel sums
+ *                       in fixed slice order.  Deterministic; changes the summation order of those tiles.
+ *   "conv_waves8"       128- / 64-wide conv tiles as 512-thread workgroups (8 waves of 64x32 / 32x32: four waves per SIMD) instead
+ *                       of 256 threads (4 waves of 64x64).  Bit-identical.
+ *   "conv1x1_persist"   1x1 stride-1 launches with more than 512 tiles (forward and data-gradient of the 1x1 layers at batch >= ~16)
+ *                       run as a persistent GEMM whose workgroups walk several tiles with the next tile's operands in flight
+ *                       during the epilogue (conv1x1_mfma.hip) instead of one workgroup per tile.  Bit-identical.
+ *   "conv_halo"         the 3x3 layers with 32 -> 64 channels (conv_1, conv_3): training forward and stride-2 data-gradient from
+ *                       an LDS halo tile with resident weights (conv9_mfma.hip, dgrad9s2_mfma.hip).  z / dx bit-identical, the
+ *                       statistics are the same sums in another (fp64) order.
+ *   "conv0_direct"      first layer (3 -> 32 channels) as a direct vector-FMA kernel when W % 32 == 0 and H % 8 == 0 instead of
+ *                       the matrix-core gather kernel.  Bit-identical.
+ *   "wgrad_fused_taps"  weight-gradients of conv_0 / conv_1 / conv_2 / conv_3 from halo tiles / streaming units (wgrad0, wgrad1,
+ *                       wgrad9) instead of the generic kernel.  Same products, other float-atomic summation order.
+ * Unknown keys return FV_ERR_INVALID.  The environment variable FV_OPTIONS="key=0,key=1" sets initial values at fv_create. */
+int fv_set_option(fv_ctx* ctx, const char* key, long long value);
+int fv_get_option(fv_ctx* ctx, const char* key, long long* value);
 /* The per-operator conv entry points (fv_conv2d_forward / fv_conv2d_dgrad) have no workspace
  * argument; a caller that wants the tail split there lends device scratch here (NULL, 0 = none;
  * 64 MiB covers every Darknet-53 shape at batch 40).  The buffer must stay valid until the calls that

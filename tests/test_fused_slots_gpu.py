@@ -259,7 +259,7 @@ def test_first_layer_direct_kernel_equals_gather_kernel(ctx, B, H, W):
 @pytest.mark.parametrize('B,H,cin,cout,k,s', [(2, 16, 128, 256, 3, 1), (3, 12, 128, 128, 3, 2), (2, 13, 256, 128, 1, 1), (2, 140, 256, 128, 3, 1),
                                             (2, 16, 64, 128, 3, 1), (2, 16, 32, 64, 3, 2), (3, 13, 64, 64, 1, 1)])
 def test_eight_wave_conv_equals_four_wave_conv(ctx, B, H, cin, cout, k, s):
-    """fv_set_conv_waves8: 512-thread workgroups (8 waves of 64x32) against 256-thread ones (4 waves of 64x64) on the
+    """option "conv_waves8": 512-thread workgroups (8 waves of 64x32) against 256-thread ones (4 waves of 64x64) on the
     128- and 64-wide tiles.  Every output element is the same k-ordered fmaf chain: forward (raw, fused epilogue, BN partial
     sums) and data-gradient are bit-identical; the fused BN-backward column sums agree to float32 rounding (the two
     row lanes of a wave are pre-added by a shuffle in the 8-wave form).  The last shape takes the tail split."""
@@ -295,7 +295,7 @@ def test_eight_wave_conv_equals_four_wave_conv(ctx, B, H, cin, cout, k, s):
 
 @pytest.mark.parametrize('B,H,s', [(2, 16, 1), (3, 13, 1), (2, 20, 2), (1, 38, 2), (5, 4, 1), (2, 48, 2), (41, 16, 1)])
 def test_halo_forward_is_bit_identical_to_the_tile_kernel(ctx, B, H, s):
-    """fv_set_conv_halo (conv9_mfma.hip: 32 -> 64 channels, 3x3, training forward): resident weights + one x halo
+    """option "conv_halo" (conv9_mfma.hip: 32 -> 64 channels, 3x3, training forward): resident weights + one x halo
     tile per 8x16-pixel unit, same k-ordered fmaf chain as conv_kernel<64,...> -> z bit-identical (whole, ragged and tiny
     units, both strides, more units than workgroups); the statistics slots hold the same column sums in another order."""
     from face_vijnana_yolov3_amd import ops
@@ -318,7 +318,7 @@ def test_halo_forward_is_bit_identical_to_the_tile_kernel(ctx, B, H, s):
 
 @pytest.mark.parametrize('B,H,ndy,bn', [(2, 32, 64, True), (3, 26, 64, True), (1, 76, 64, False), (2, 16, 64, True), (41, 32, 64, True), (2, 44, 64, False)])
 def test_halo_stride2_dgrad_is_bit_identical_to_the_tile_kernel(ctx, B, H, ndy, bn):
-    """fv_set_conv_halo, data-gradient side (dgrad9s2_mfma.hip: the stride-2 3x3 layer with 32 -> 64 channels): the four
+    """option "conv_halo", data-gradient side (dgrad9s2_mfma.hip: the stride-2 3x3 layer with 32 -> 64 channels): the four
     parity classes from one dy halo tile with the transposed weights resident in LDS; same k-ordered chains as
     conv_kernel<32,4,1> -> dx bit-identical (whole and ragged units, more units than workgroups); with the fused
     BN-backward reduction the slots hold the same d-beta / d-gamma sums in another order, and match float64."""
@@ -398,3 +398,64 @@ def test_halo_stride2_dgrad_next_to_the_2_gib_output_bound(ctx, B):
     finally:
         ctx.set_conv_halo(True)
     assert torch.equal(dx[B - 3:], part0)
+
+
+# rows (B x H x H), cin, cout: every shape has more than 512 tiles, so the persistent form is taken and workgroups walk 2+ tiles
+PERSIST_CASES = [
+    (7, 100, 256, 128),     # 547 tiles of 128x128, 8 K steps, ragged last M tile (70 000 rows)
+    (5, 84, 128, 256),      # 276 x 2 tiles, 4 K steps: two N tiles per A panel
+    (5, 84, 96, 256),       # 3 K steps: odd step count (the loop is unrolled by two)
+    (9, 96, 32, 128),       # ONE K step per tile, 648 tiles
+    (9, 96, 64, 128),       # two K steps
+    (9, 92, 128, 64),       # 64-wide tiles (4 x 2 waves), 596 tiles
+    (3, 64, 64, 1024),      # 96 x 8 tiles: eight N tiles per A panel
+]
+
+
+@pytest.mark.parametrize('B,H,cin,cout', PERSIST_CASES)
+def test_persistent_1x1_conv_equals_the_tile_kernel(ctx, B, H, cin, cout):
+    """option "conv1x1_persist" (conv1x1_mfma.hip): 1x1 launches with more than 512 tiles as a persistent GEMM whose workgroups
+    walk several tiles.  Same tile shape, K order and MFMA sequence per output element as conv_kernel: the training forward (raw
+    z + per-tile partial sums), the inference epilogue (affine + LeakyReLU + residual) and the data-gradient with addend and fused
+    BN-backward reduction are BIT-IDENTICAL to the one-tile-per-workgroup launches; the fp64 slot sums hold the same per-tile
+    column sums, added in another order.  And the result is right (float64 reference)."""
+    from face_vijnana_yolov3_amd import ops
+    x = _rand((B, H, H, cin), 211).cuda(); w = _rand((cout, 1, 1, cin), 212, -0.2, 0.2).cuda()
+    dy = _rand((B, H, H, cout), 213).cuda(); add_in = _rand((B, H, H, cin), 214).cuda(); add_out = _rand((B, H, H, cout), 219).cuda()
+    z2 = _rand((B, H, H, cin), 215, -2.0, 2.0).cuda(); v2 = [v.cuda() for v in _bn_vectors(cin, 216)]
+    scale = _rand((cout,), 217, 0.5, 1.5).cuda(); shift = _rand((cout,), 218).cuda()
+    res = {}
+    assert ctx.get_option('conv1x1_persist') == 1          # the default
+    try:
+        for on in (True, False):
+            ctx.set_option('conv1x1_persist', on)
+            out, psum, psq = ops.conv2d_forward(ctx, x, w, stride=1, stats=True)
+            fslots = ops.stat_slots(cout, 'cuda')
+            zs = ops.conv2d_forward_slots(ctx, x, w, 1, fslots)
+            fused = ops.conv2d_forward(ctx, x, w, 1, scale, shift, 0.1, add_out)
+            plain = ops.conv2d_dgrad(ctx, dy, w, (H, H), 1)
+            bslots = ops.stat_slots(cin, 'cuda')
+            dx = ops.conv2d_dgrad_bnred(ctx, dy, w, (H, H), 1, z2, *v2, bslots, addend=add_in) if (256 % cin == 0 or cin % 256 == 0) else plain
+            torch.cuda.synchronize()
+            res[on] = (out, psum, psq, zs, fused, plain, dx, fslots.sum(0), bslots.sum(0))
+    finally:
+        ctx.set_option('conv1x1_persist', 1)
+    for i in range(7):
+        assert torch.equal(res[True][i], res[False][i]), i
+    for i in (7, 8):
+        mag = res[False][i].abs().max().item()
+        torch.testing.assert_close(res[True][i], res[False][i], rtol=1e-12, atol=1e-12 * max(mag, 1.0))
+    ref = _ref_conv(x.cpu().double(), w.cpu().double(), 1, 1); bound = _ref_conv(x.cpu().double().abs(), w.cpu().double().abs(), 1, 1)
+    assert ((res[True][0].cpu().double() - ref).abs() <= 2e-6 * bound + 1e-6).all()
+
+
+def test_unknown_option_is_refused(ctx):
+    from face_vijnana_yolov3_amd._lib import FvError
+    with pytest.raises(FvError):
+        ctx.set_option('no_such_switch', 1)
+    with pytest.raises(FvError):
+        ctx.get_option('no_such_switch')
+    for key in ('overlap', 'tail_split', 'conv_waves8', 'conv1x1_persist', 'conv_halo', 'conv0_direct', 'wgrad_fused_taps'):
+        assert ctx.get_option(key) == 1
+        ctx.set_option(key, 0); assert ctx.get_option(key) == 0
+        ctx.set_option(key, 1)

@@ -297,7 +297,7 @@ def test_bucketed_side_stream_path_equals_plain(eng):
 
 
 def test_side_stream_overlap_equals_serial(eng):
-    """fv_set_overlap: wgrad on the side stream vs everything on one stream -- same gradients (up to
+    """fv_set_option("overlap"): wgrad on the side stream vs everything on one stream -- same gradients (up to
     the float-atomic summation order inside dW), same bucket protocol."""
     p64, s64, x, yt = _setup(13, 4, 96)
     res = []
@@ -319,7 +319,7 @@ def test_side_stream_overlap_equals_serial(eng):
 
 
 def test_tail_split_on_off(eng):
-    """fv_set_tail_split: tiles of the last partial round cut into K slices + fix-up kernel.  Only the
+    """fv_set_option("tail_split"): tiles of the last partial round cut into K slices + fix-up kernel.  Only the
     fp32 summation order of those tiles changes: inference outputs agree to rounding, both settings meet
     the oracle bound in training, and each setting is run-to-run deterministic in the forward pass."""
     from oracle import net_oracle as no

@@ -151,7 +151,7 @@ WGRAD_CASES = [
 
 
 def test_first_layer_wgrad_halo_equals_gather(ctx):
-    """wgrad0_mfma.hip against the element-wise gather kernel (fv_set_wgrad_fused_taps(0)): same products, other summation order."""
+    """wgrad0_mfma.hip against the element-wise gather kernel (option "wgrad_fused_taps" = 0): same products, other summation order."""
     from face_vijnana_yolov3_amd import ops
     for (B, H) in [(3, 48), (2, 21)]:
         x = _rand((B, H, H, 3), 83).cuda(); dy = _rand((B, H, H, 32), 84).cuda()
@@ -165,7 +165,7 @@ def test_first_layer_wgrad_halo_equals_gather(ctx):
 
 
 def test_wgrad_fused_taps_equals_generic(ctx):
-    """fv_set_wgrad_fused_taps: the nine-tap kernel and the one-workgroup-per-tap kernel form the same products; only the
+    """option "wgrad_fused_taps": the nine-tap kernel and the one-workgroup-per-tap kernel form the same products; only the
     order of the float additions differs."""
     from face_vijnana_yolov3_amd import ops
     for (B, H, s) in [(3, 40, 1), (2, 52, 2)]:
@@ -348,7 +348,7 @@ def test_fd_loss_and_grad(ctx):
 
 @pytest.mark.parametrize('B,H,cin,cout,k,s', [(2, 13, 128, 256, 3, 1), (2, 16, 32, 64, 3, 2), (3, 13, 64, 32, 1, 1), (2, 13, 1024, 6, 3, 1)])
 def test_four_and_eight_wave_tiles_are_bit_identical(ctx, B, H, cin, cout, k, s):
-    """fv_set_conv_waves8: 2x4 waves of 64x32 (default) against 2x2 waves of 64x64 -- the same k-ordered fmaf chain per output
+    """option "conv_waves8": 2x4 waves of 64x32 (default) against 2x2 waves of 64x64 -- the same k-ordered fmaf chain per output
     element, so outputs (incl. zero padding at the borders) and data-gradients are bit-identical."""
     from face_vijnana_yolov3_amd import ops
     x = _rand((B, H, H, cin), 71).cuda(); w = _rand((cout, k, k, cin), 72).cuda()
