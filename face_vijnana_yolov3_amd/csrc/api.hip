@@ -191,16 +191,7 @@ int fv_create(int device, void* stream, fv_ctx** out) {
         const char* pr = getenv("FV_SIDE_PRIORITY");
         int least = 0, greatest = 0;
         const bool range = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
-        // FV_SIDE_CUS=n (experiment): the side stream may only use n of the 256 CUs (bits 0 .. n-1 of the queue's CU mask,
-        // which the driver deals round-robin over the 8 XCDs), so that the compute stream's HBM-bound BN passes find free CUs while
-        // a weight-gradient runs.  A masked stream has the default priority.
-        const char* cus = getenv("FV_SIDE_CUS");
-        const int ncu = cus ? atoi(cus) : 0;
-        if (ncu > 0 && ncu < 256) {
-            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
-            ok = hipExtStreamCreateWithCUMask(&c->side, 8, mask) == hipSuccess;
-        } else if (range && !(pr && pr[0] == 'd'))
+        if (range && !(pr && pr[0] == 'd'))
             ok = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, (pr && pr[0] == 'h') ? greatest : least) == hipSuccess;
         else
             ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;

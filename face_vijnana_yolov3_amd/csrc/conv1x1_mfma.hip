@@ -199,6 +199,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4) void conv1x1_persist_ker
             }
         }
         float* Cs = smem;
+        constexpr int C4 = BN / 4;
+        constexpr int NP = BM * C4 / NTH, GP = NP < 4 ? NP : 4;
+        static_assert(NP % GP == 0, "epilogue grouping");
+        constexpr bool bnred = BNRED;
+        const bool addon = (a.epi & FV_EPI_ADD) != 0;
         __syncthreads();         // (the K loop's last barrier already separates the operand reads from these writes; kept for the `red` reads above)
 #pragma unroll
         for (int j = 0; j < NB; ++j)
@@ -208,13 +213,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4) void conv1x1_persist_ker
                 for (int r = 0; r < 16; ++r)
                     Cs[(wm_e * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half_e) * BN + wn_e * WTN + j * 32 + lc_e] = acc[i][j][r];
         __syncthreads();
-        constexpr int C4 = BN / 4;
-        constexpr bool bnred = BNRED;
         BnRedAcc br;
         br.init(a, n0 + (te % C4) * 4, bnred && n0 + (te % C4) * 4 < a.Nout);
-        constexpr int NP = BM * C4 / NTH, GP = NP < 4 ? NP : 4;
-        static_assert(NP % GP == 0, "epilogue grouping");
-        const bool addon = (a.epi & FV_EPI_ADD) != 0;
 #pragma unroll
         for (int p0 = 0; p0 < NP; p0 += GP) {
             int offn[GP]; bool okp[GP];

@@ -16,13 +16,31 @@
 //    per wave instruction; the caller zeroes dw once per step
 //  * chunk loop: global loads one chunk ahead, LDS fragments one k-pair ahead (register double buffer)
 #include <type_traits>
-#include "conv.h"
+#include "conv_tile.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KP = 32;  // pixels per chunk
+
+// Phase stamps (tools/build_variant.sh stamps -DFV_CONV_STAMPS; tools/conv_phases.py): entry, first chunk staged, chunk loop done, atomics issued
+#ifdef FV_CONV_STAMPS
+constexpr int WSTAMP_WGS = 8192;
+__device__ unsigned long long g_wstamps[WSTAMP_WGS * 5];
+#define FV_WSTAMP(k)                                                                          \
+    do {                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < WSTAMP_WGS) {                                    \
+            g_wstamps[blockIdx.x * 5 + (k)] = wall_clock64();                                 \
+            if ((k) == 0) {                                                                   \
+                unsigned hw_, xcc_;                                                           \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));             \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));           \
+                g_wstamps[blockIdx.x * 5 + 4] = ((unsigned long long)xcc_ << 32) | hw_;        \
+            }                                                                                 \
+        }                                                                                     \
+    } while (0)
+#else
+#define FV_WSTAMP(k) do {} while (0)
+#endif
 
 // NW = 8 (QUAD only): 512-thread workgroups, 2 x 4 waves of 64 x 32 -- four waves per SIMD instead of two, same arithmetic.
 template <int TM, int TN, bool QUAD, bool GATHER, int NW = 4>
@@ -39,6 +57,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
     __shared__ __attribute__((aligned(16))) float Bs[2][KP * LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    FV_WSTAMP(0);
     const int wm = QUAD ? wave / (NW / 2) : 0, wn = QUAD ? wave % (NW / 2) : 0;
     const int NTc = GATHER ? 1 : a.Cin / TN;
     // Workgroup ids go round-robin over the 8 XCDs (one L2 each).  All (tile, tap) workgroups of one
@@ -235,6 +254,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
         load();
         stage(0);
         __syncthreads();
+        FV_WSTAMP(1);
         auto body = [&](int ch, auto odd) {
             constexpr bool ODD = decltype(odd)::value;
             const float* Ac = As[ODD ? 1 : 0]; const float* Bc = Bs[ODD ? 1 : 0];
@@ -286,6 +306,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
     }
     }
 
+    FV_WSTAMP(2);
     const int half = lane >> 5, lc = lane & 31;
     const int Kw = GATHER ? 9 * a.Cin : 0;
 #pragma unroll
@@ -304,6 +325,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_kernel(const FvWgradArgs a, 
                     }
                 }
             }
+    FV_WSTAMP(3);
 }
 
 template <int TM, int TN, bool QUAD, bool GATHER>
@@ -317,6 +339,8 @@ int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
     // kernels where all the parallelism comes from the split.
     //  * tiles < 64: splits come in groups of 8, one per XCD (see the kernel): rounds of 64 slots
     //  * tiles >= 64: a split already fills an XCD; plain order, rounds of all 512 slots
+    // (round 5 re-measured the 1x1 bound: 12 or 8 chunks per workgroup fill all 512 slots and move the 52x52 / 26x26 / 13x13 launches
+    // by +3 / -4 / +5 %: the atomics of twice as many workgroups cost what the idle slots cost)
     const int min_chunks = ntap == 1 ? 16 : 8;
     const int pinned = tiles < 64 ? 1 : 0;
     const int unit = pinned ? 8 : 1, slots = pinned ? 64 : 512;
@@ -351,6 +375,15 @@ int launch_w(fv_ctx* ctx, const FvWgradArgs& a) {
 }
 
 }  // namespace
+
+#ifdef FV_CONV_STAMPS
+extern "C" int fv_debug_wgrad_stamps(fv_ctx* ctx, unsigned long long* out, int nwg) {
+    if (!ctx || !out || nwg < 1 || nwg > WSTAMP_WGS) return FV_ERR_INVALID;
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FV_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamps), (size_t)nwg * 5 * sizeof(unsigned long long)));
+    return FV_OK;
+}
+#endif
 
 int fv_wgrad_launch(fv_ctx* ctx, const FvWgradArgs& a) {
     FV_REQUIRE(ctx, a.x && a.dy && a.dw, "wgrad: NULL tensor");

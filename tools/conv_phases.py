@@ -11,6 +11,7 @@ medians, the start skew and what a CU's two slots did over time."""
 import ctypes
 import os
 import sys
+import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
@@ -20,12 +21,12 @@ from face_vijnana_yolov3_amd import ops  # noqa: E402
 from face_vijnana_yolov3_amd._lib import Context, lib  # noqa: E402
 
 
-def stamps(ctx, nwg):
+def stamps(ctx, nwg, fn='fv_debug_conv_stamps'):
     buf = np.zeros((nwg, 5), np.uint64)
-    L = lib()
-    L.fv_debug_conv_stamps.restype = ctypes.c_int
-    L.fv_debug_conv_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-    ctx.check(L.fv_debug_conv_stamps(ctx.handle, buf.ctypes.data_as(ctypes.c_void_p), nwg), 'fv_debug_conv_stamps')
+    f = getattr(lib(), fn)
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    ctx.check(f(ctx.handle, buf.ctypes.data_as(ctypes.c_void_p), nwg), fn)
     return buf
 
 
@@ -58,6 +59,7 @@ def report(name, st, flops):
 def main():
     ctx = Context(0)
     ctx.set_conv_scratch(torch.empty(64 << 20, dtype=torch.uint8, device='cuda'))
+    ctx.set_option('conv1x1_persist', 0)        # the stamps are per workgroup = per tile in the one-tile kernel only
     B = 40
     g = torch.Generator(device='cuda').manual_seed(0)
     for (H, cin, cout) in ((52, 256, 128), (26, 512, 256), (13, 1024, 512)):
@@ -83,6 +85,22 @@ def main():
         torch.cuda.synchronize()
         nt = ((M + 127) // 128) * ((cin + 127) // 128)
         report('dgrad 1x1 r M%d N%d K%d' % (M, cin, cout), stamps(ctx, min(nt * 3, 32768))[:nt], 2.0 * M * cin * cout)
+    # weight-gradients of the 1x1 layers (x: cin channels, dy: cout channels)
+    for (H, cin, cout) in ((52, 256, 128), (26, 512, 256), (13, 1024, 512), (52, 128, 256)):
+        M = B * H * H
+        x = torch.rand((B, H, H, cin), device='cuda', generator=g)
+        dy = torch.rand((B, H, H, cout), device='cuda', generator=g)
+        k = 1 if (cin, cout) != (128, 256) else 3
+        for _ in range(3):
+            ops.conv2d_wgrad(ctx, x, dy, cout, k)
+        torch.cuda.synchronize()
+        time.sleep(0.02)                                 # 2e6 ticks: the measured launch's stamps are the only ones of the last 2 ms
+        ops.conv2d_wgrad(ctx, x, dy, cout, k)
+        torch.cuda.synchronize()
+        st = stamps(ctx, 8192, 'fv_debug_wgrad_stamps')
+        st = st[st[:, 3] > st[:, 0]]
+        live = st[(st[:, 0] + np.uint64(200000) >= st[:, 0].max())]
+        report('wgrad %dx%d M%d N%d C%d' % (k, k, M, cout, cin), live, 2.0 * M * cin * cout * k * k)
     # a 3x3 layer for scale
     H, cin, cout = 52, 128, 256
     M = B * H * H
