@@ -38,15 +38,30 @@ IMAGE_SIZE = 416
 PER_GPU_BATCH = 40
 FP32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s is what a float4 copy reaches)
-DOMINANT_RE = r'conv_kernel<128, ?2, ?[24], ?false'   # library label 'conv_kernel<128,2,4,false>' / rocprofv3 name
+# The dominant kernel FAMILY: the 128x128-tile fp32-MFMA implicit GEMM of every forward / data-gradient launch with >= 128 output
+# channels.  Since round 5 its 1x1 launches with more than 512 tiles run as conv1x1_persist_kernel<128,...> (the same tile, K loop
+# and epilogue, persistent over tiles; conv1x1_mfma.hip), so the family is two kernel names: the roofline is computed over BOTH
+# (the same 92 launches per step as in rounds 1-4) and `parts` gives each name on its own.
+DOMINANT_RE = r'conv_kernel<128, ?2, ?[24], ?false|conv1x1_persist_kernel<128'   # library labels / rocprofv3 names
+
+
+def dominant_parts(d):
+    """{name: record} of the dominant family's kernels in a per-kernel dict."""
+    import re
+    return {k: v for k, v in d.items() if re.match(DOMINANT_RE, k)}
 
 
 def dominant(d):
-    """(key, value) of the 128-wide non-gather conv kernel in a per-kernel dict, whichever wave layout ran."""
-    import re
-    return next(((k, v) for k, v in d.items() if re.match(DOMINANT_RE, k)), (None, None))
+    """(name, record) of the dominant family in a per-kernel profile dict: launches, ms, flops and bytes summed over its kernels."""
+    parts = dominant_parts(d)
+    if not parts:
+        return None, None
+    tot = {f: sum(v[f] for v in parts.values()) for f in ('launches', 'ms', 'flops', 'bytes')}
+    return ' + '.join(sorted(parts)), tot
+
+
 HPS = dict(lr=1e-4, beta_1=0.99, beta_2=0.99, decay=0.0)  # reference face_vijnana_yolov3.json:12-15
-TRAFFIC_FILES = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
+TRAFFIC_FILES = ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json')
 
 
 def parse():
@@ -330,7 +345,7 @@ def test_loop_bench(device, S, n_img=256, head='single'):
     return dict(unit='images/sec', eval_batch_1=out['batch1'], eval_batch_16=out['batch16'], eval_batch_32=out['batch32'], images=n_img, csv_rows=rows,
                 loader_threads=default_threads, eval_batch_32_by_loader_threads=sweep, host_cpus=host_cpus(),
                 path='FaceDetector.test(): %d synthetic JPEGs (768x1024 .. 720x1280), Huffman decoding on hps.loader_threads host threads (default '
-                     'min(32, cpus / 4)) into reused pinned buffers one batch ahead, fv_jpeg_reconstruct_batch, fv_letterbox_batch, '
+                     'half the usable CPUs, 4 .. 32) into reused pinned buffers one batch ahead, fv_jpeg_reconstruct_batch, fv_letterbox_batch, '
                      'fv_forward_infer, fv_decode_nms, back-projection, csv' % n_img)
 
 
@@ -476,23 +491,25 @@ def rccl_world1_rehearsal(eng, x, y, steps=10):
 
 
 def pmc_traffic(B, S):
-    """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes --
-    only if the kernel sources are still the ones that were profiled (fingerprint recorded with the pass)."""
+    """HBM-side bytes per launch of the dominant kernel family from the newest committed rocprofv3 PMC passes (launch-weighted
+    over its kernels) -- only if the kernel sources are still the ones that were profiled (fingerprint recorded with the pass)."""
     from face_vijnana_yolov3_amd.build import source_fingerprint
     for name in TRAFFIC_FILES:
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', name)))
         except (OSError, ValueError):
             continue
-        tk = dominant(tj)[1]
-        if not tk or B != PER_GPU_BATCH or S != IMAGE_SIZE:
+        parts = dominant_parts({k: v for k, v in tj.items() if isinstance(v, dict)})
+        if not parts or B != PER_GPU_BATCH or S != IMAGE_SIZE:
             return None, None
         if tj.get('_source_fingerprint') != source_fingerprint():
             return None, 'profiles/%s was taken on other kernel sources (fingerprint %s, now %s): traffic not reported' % (
                 name, tj.get('_source_fingerprint'), source_fingerprint())
-        return round((tk['fetch_MB_per_launch'] + tk['write_MB_per_launch']) * 1e6), (
+        n = sum(v['launches_in_2_steps'] for v in parts.values())
+        mb = sum((v['fetch_MB_per_launch'] + v['write_MB_per_launch']) * v['launches_in_2_steps'] for v in parts.values())
+        return round(mb / n * 1e6), (
             'profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 (gfx950 correction); '
-            'fabric-side requests, Infinity-Cache hits included' % name)
+            'fabric-side requests, Infinity-Cache hits included; launch-weighted over %s' % (name, ' + '.join(sorted(parts))))
     return None, None
 
 
@@ -706,7 +723,12 @@ def main():
                             mode='exclusive: instrumented steps run with fv_set_option("overlap", 0)',
                             launches_per_step=dom['launches'] // max(args.profile_steps, 1),
                             avg_launch_ms=round(dom['ms'] / dom['launches'], 4),
-                            gflop_per_launch=round(dom['flops'] / dom['launches'] / 1e9, 3))
+                            gflop_per_launch=round(dom['flops'] / dom['launches'] / 1e9, 3),
+                            parts={k: dict(launches_per_step=v['launches'] // max(args.profile_steps, 1),
+                                           avg_launch_ms=round(v['ms'] / v['launches'], 4),
+                                           gflop_per_launch=round(v['flops'] / v['launches'] / 1e9, 3),
+                                           achieved=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2))
+                                   for k, v in dominant_parts(prof).items()})
         kernels = {k: dict(launches=v['launches'] // max(args.profile_steps, 1),
                            ms_per_step=round(v['ms'] / max(args.profile_steps, 1), 3),
                            tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['flops'] and v['ms'] else None,

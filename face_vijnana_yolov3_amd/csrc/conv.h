@@ -47,6 +47,7 @@ struct FvConvArgs {
     int tail_f;        // >1: tail split active (set by the launcher): tiles >= tail_full are cut into tail_f K-slices
     int tail_full;
     float* tail_slab;  // [tail tiles * tail_f][128][BN] raw partial tiles
+    int bm64;          // 1: 64-row tiles (fv_conv_bm64: small-M inference launches with 128-wide tiles)
     int narrow;        // 1: 128x32 tiles whatever Nout (small-M 1x1 layers of the inference path, fv_conv_narrow)
     int ksplit;        // >1: blockIdx.y owns a slice of the K steps and stores its raw partial to out + y*split_stride
     long long split_stride;
@@ -57,7 +58,9 @@ struct FvConvArgs {
 // Number of M tiles (rows of psum/psq) the conv launch will use for this problem.
 int fv_conv_mtiles(int M, int Nout);
 // K-split factor the small-M inference path uses for a problem (1 = no split).
-int fv_conv_choose_ksplit(int M, int Nout, int ksteps);
+int fv_conv_choose_ksplit(int M, int Nout, int ksteps, bool allow_bm64 = true);
+// Small-M inference: 64-row instead of 128-row tiles for a launch with 128-wide tiles when that leaves fewer padded rows.
+bool fv_conv_bm64(int M, int Nout, int ksteps);
 // Small-M inference: a 1x1 layer (8..16 K steps) whose 128-wide tiling gives fewer than 64 tiles runs on 128x32 tiles WITHOUT a K
 // split -- one launch instead of conv + split-K finish (a kernel costs >= 3.7 us on MI355X however little it does).
 bool fv_conv_narrow(int M, int Nout, int ksteps);

@@ -46,8 +46,11 @@ __device__ unsigned long long g_stamps[STAMP_WGS * 5];
 #define FV_STAMP(k) do {} while (0)
 #endif
 
-template <int BN, int WAVES_M, int WAVES_N, bool GATHER>
+// BM_: rows of the tile.  128 everywhere except the K-split launches of the small-M inference path whose row count leaves a 128-row
+// tiling more padding than a 64-row one (fv_conv_bm64: 13x13, 26x26, 52x52 pixels at batch 1): 64 x 128 tiles, 2 x 4 waves of 32 x 32.
+template <int BN, int WAVES_M, int WAVES_N, bool GATHER, int BM_ = 128>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_kernel(const FvConvArgs a) {
+    constexpr int BM = BM_;                // (shadows the 128 of conv_tile.h inside this kernel)
     // NTH threads: 4 waves (2x2, each 64x64) or 8 waves (2x4, each 64x32: two more waves per SIMD to cover barriers and LDS latency)
     constexpr int NTH = 64 * WAVES_M * WAVES_N;
     constexpr int APT = BM * 8 / NTH;      // A-tile float4 loads per thread
@@ -526,13 +529,14 @@ __global__ __launch_bounds__(1024) void conv_tail_fixup_kernel(const FvConvArgs 
     }
 }
 
-template <int BN, int WM_, int WN_, bool G>
+template <int BN, int WM_, int WN_, bool G, int BM_ = 128>
 int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
+    constexpr int BM = BM_;
     constexpr int NTH = 64 * WM_ * WN_;
     const int MT = (a.M + BM - 1) / BM, NT = (a.Nout + BN - 1) / BN;
     dim3 grid(MT * NT, a.ksplit > 1 ? a.ksplit : 1, a.nclass);
     static const std::string name_s = "conv_kernel<" + std::to_string(BN) + "," + std::to_string(WM_) + "," + std::to_string(WN_) +
-                                      (G ? ",true>" : ",false>");   // rocprofv3's name up to the first four template arguments
+                                      (G ? ",true" : ",false") + (BM_ == 128 ? ">" : "," + std::to_string(BM_) + ">");   // rocprofv3's name
     static const char* name = name_s.c_str();
     FvProfScope ps(ctx, name, "M" + std::to_string(a.M) + " N" + std::to_string(a.Nout) + " K" + std::to_string(a.taps[0].n * a.Cin) +
                                   (a.nclass > 1 ? " s2" : "") + (a.ksplit > 1 ? " ks" + std::to_string(a.ksplit) : "") + ((a.epi & FV_EPI_BNRED) ? " r" : ""),
@@ -542,7 +546,7 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
     FvConvArgs b = a;
     if (b.ksplit < 1) b.ksplit = 1;
     b.tail_f = 1; b.tail_full = 0; b.tail_slab = nullptr;
-    if constexpr (!G && BN == 128) {
+    if constexpr (!G && BN == 128 && BM_ == 128) {
         // tail split: only with caller scratch (network-level calls), whole-lattice launches, 16-byte rows
         if (ctx->tail_split && ctx->tail_slab && b.ksplit == 1 && a.nclass == 1 && (a.Nout & 3) == 0) {
             int tf = 1, full = 0; long long need = 0;
@@ -558,7 +562,7 @@ int launch_cfg(fv_ctx* ctx, const FvConvArgs& a) {
             }
         }
     }
-    hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G>), grid, dim3(NTH), 0, ctx->stream, b);
+    hipLaunchKernelGGL((conv_kernel<BN, WM_, WN_, G, BM_>), grid, dim3(NTH), 0, ctx->stream, b);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }
@@ -582,10 +586,20 @@ bool fv_conv_narrow(int M, int Nout, int ksteps) {
     return mt * ((Nout + 127) / 128) < 64 && mt * (Nout / 32) >= 48;
 }
 
-int fv_conv_choose_ksplit(int M, int Nout, int ksteps) {
+// Small-M inference, 128-wide tiles: 64-row tiles when the launch is in the small-M regime (fewer than 192 tiles of 128 rows, at
+// least 8 K steps) and they leave fewer padded rows than 128-row ones (169 rows: 192 instead of 256; 676: 704 / 768; 2704: 2752 /
+// 2816) -- padded rows are multiplied like real ones, and the finer tiling needs fewer K slices (fewer slabs for the finish kernel).
+bool fv_conv_bm64(int M, int Nout, int ksteps) {
+    if (Nout <= 64 || ksteps < 8 || fv_conv_narrow(M, Nout, ksteps)) return false;
+    if (((M + BM - 1) / BM) * ((Nout + 127) / 128) >= 192) return false;
+    return (M + 63) / 64 * 64 < (M + 127) / 128 * 128;
+}
+
+int fv_conv_choose_ksplit(int M, int Nout, int ksteps, bool allow_bm64) {
     if (fv_conv_narrow(M, Nout, ksteps)) return 1;
     const int bn = Nout > 64 ? 128 : (Nout > 32 ? 64 : 32);
-    const int tiles = ((M + BM - 1) / BM) * ((Nout + bn - 1) / bn);
+    const int bm = allow_bm64 && fv_conv_bm64(M, Nout, ksteps) ? 64 : BM;
+    const int tiles = ((M + bm - 1) / bm) * ((Nout + bn - 1) / bn);
     if (tiles >= 192 || ksteps < 8) return 1;         // enough tiles to fill 256 CUs, or nothing to split
     int want = (512 + tiles - 1) / tiles, cap = ksteps / 4;
     int ks = want < cap ? want : cap;
@@ -678,6 +692,7 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
     if (ctx->conv1x1_persist && fv_conv1x1_persist_ok(a)) return fv_conv1x1_persist_launch(ctx, a);
     // 128-wide tiles: 8 waves (2 x 4, each 64 x 32) put four waves on every SIMD instead of two: the same per-element fmaf
     // chain (bit-identical outputs), 129 against 121 TF on the 52x52 layers
+    if (a.Nout > 64 && a.bm64) return launch_cfg<128, 2, 4, false, 64>(ctx, a);
     if (a.Nout > 64) return ctx->conv_waves8 ? launch_cfg<128, 2, 4, false>(ctx, a) : launch_cfg<128, 2, 2, false>(ctx, a);
     if (a.Nout > 32) return ctx->conv_waves8 ? launch_cfg<64, 4, 2, false>(ctx, a) : launch_cfg<64, 2, 2, false>(ctx, a);
     return launch_cfg<32, 4, 1, false>(ctx, a);

@@ -160,8 +160,10 @@ Plan make_plan(void* base, int B, int S, bool training) {
         for (int l = 1; l < p.nl; ++l) {
             const auto& d = N.L[l];
             size_t rows = (size_t)B * (S / d.out_div) * (S / d.out_div);
-            int ks = fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32);
-            if (ks > 1 && ks * rows * d.cout > max_slab) max_slab = ks * rows * d.cout;
+            for (int bm64 = 0; bm64 < 2; ++bm64) {       // either setting of option "conv_bm64"
+                const int ks = fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32, bm64 != 0);
+                if (ks > 1 && ks * rows * d.cout > max_slab) max_slab = ks * rows * d.cout;
+            }
         }
         p.slab = max_slab ? c.take(max_slab) : nullptr;
     }
@@ -259,7 +261,7 @@ static int forward_impl(fv_ctx* ctx, const float* params, const float* bn_state,
         float* out = (feat && l == nb - 1) ? feat : p.G[iout];
         const float* w = l == 0 ? p.w0p : params + d.w_off;
         const long long rows = (long long)batch * (H / d.stride) * (H / d.stride);
-        const int ks = l == 0 ? 1 : fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32);
+        const int ks = l == 0 ? 1 : fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32, ctx->conv_bm64);
         if (ks > 1) {
             // small M (batch-1 latency): K-split partial slabs, summed in fixed order by the finish kernel
             if (int rc = fv_op_conv_forward(ctx, cur, w, batch, H, H, d.cin, d.cout, d.ksize, d.stride, 0, nullptr, nullptr, 0.f,

@@ -102,8 +102,10 @@ YPlan yplan(void* base, const YNet& N, int B, int S) {
         size_t rows = (size_t)B * (S / d.out_div) * (S / d.out_div);
         if (rows * d.cout > max_act) max_act = rows * d.cout;
         if (l > 0) {
-            int ks = fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32);
-            if (ks > 1 && ks * rows * d.cout > max_slab) max_slab = ks * rows * d.cout;
+            for (int bm64 = 0; bm64 < 2; ++bm64) {       // either setting of option "conv_bm64"
+                const int ks = fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32, bm64 != 0);
+                if (ks > 1 && ks * rows * d.cout > max_slab) max_slab = ks * rows * d.cout;
+            }
         }
     }
     for (int i = 0; i < 3; ++i) p.G[i] = c.take(max_act);
@@ -253,7 +255,7 @@ int fv_yolov3_forward(fv_ctx* ctx, const float* params, const float* bn_state, c
         const float* w = d.darknet_index == 0 ? p.w0p : params + d.w_off;
         const float* sc = d.has_bn ? p.scale + d.mean_off / 2 : nullptr;
         const float* sh = d.has_bn ? p.shift + d.mean_off / 2 : params + d.beta_off;
-        const int ks = d.darknet_index == 0 ? 1 : fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32);
+        const int ks = d.darknet_index == 0 ? 1 : fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32, ctx->conv_bm64);
         if (ks > 1) {
             if (int rc = fv_op_conv_forward(ctx, in, w, batch, H, H, d.cin, d.cout, d.ksize, d.stride, 0, nullptr, nullptr, 0.f, nullptr,
                                             p.slab, nullptr, nullptr, ks)) return rc;

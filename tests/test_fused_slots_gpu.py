@@ -455,7 +455,34 @@ def test_unknown_option_is_refused(ctx):
         ctx.set_option('no_such_switch', 1)
     with pytest.raises(FvError):
         ctx.get_option('no_such_switch')
-    for key in ('overlap', 'tail_split', 'conv_waves8', 'conv1x1_persist', 'conv_halo', 'conv0_direct', 'wgrad_fused_taps'):
+    for key in ('overlap', 'tail_split', 'conv_waves8', 'conv1x1_persist', 'conv_bm64', 'conv_halo', 'conv0_direct', 'wgrad_fused_taps'):
         assert ctx.get_option(key) == 1
         ctx.set_option(key, 0); assert ctx.get_option(key) == 0
         ctx.set_option(key, 1)
+
+
+@pytest.mark.parametrize('B,H,cin,cout,k,s', [(1, 13, 512, 1024, 3, 1), (1, 26, 256, 512, 3, 1), (1, 52, 128, 256, 3, 1), (1, 26, 512, 1024, 3, 2),
+                                            (3, 13, 1024, 512, 1, 1), (1, 38, 256, 512, 3, 1)])
+def test_64_row_tiles_equal_128_row_tiles(ctx, B, H, cin, cout, k, s):
+    """option "conv_bm64": small-M inference launches (fewer than 192 tiles of 128 x 128) whose row count pads less with 64-row
+    tiles run conv_kernel<128,2,4,false,64>.  Unsplit (the operator entry point), every output element is the same k-ordered fmaf
+    chain as in the 128-row tiling: bit-identical with the fused inference epilogue (affine + LeakyReLU + residual), and right."""
+    from face_vijnana_yolov3_amd import ops
+    x = _rand((B, H, H, cin), 311).cuda(); w = _rand((cout, k, k, cin), 312, -0.1, 0.1).cuda()
+    Ho = H // s
+    scale = _rand((cout,), 313, 0.5, 1.5).cuda(); shift = _rand((cout,), 314).cuda(); add = _rand((B, Ho, Ho, cout), 315).cuda()
+    res = {}
+    try:
+        for on in (True, False):
+            ctx.set_option('conv_bm64', on)
+            res[on] = ops.conv2d_forward(ctx, x, w, s, scale, shift, 0.1, add)
+            torch.cuda.synchronize()
+    finally:
+        ctx.set_option('conv_bm64', 1)
+    assert torch.equal(res[True], res[False])
+    ref = _ref_conv(x.cpu().double(), w.cpu().double(), k, s); bound = _ref_conv(x.cpu().double().abs(), w.cpu().double().abs(), k, s)
+    pre = ref * scale.cpu().double() + shift.cpu().double()
+    want = torch.where(pre > 0, pre, 0.1 * pre) + add.cpu().double()
+    tol = 2e-6 * bound * scale.cpu().double().abs() + 1e-5
+    # (elements within rounding of the LeakyReLU kink may take the other slope in float32: bounded by the same tolerance x 1)
+    assert ((res[True].cpu().double() - want).abs() <= tol + 0.9 * (pre.abs() <= tol).double() * pre.abs()).all()

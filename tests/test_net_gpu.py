@@ -260,6 +260,26 @@ def test_bn_zero_debias_moving_statistics(eng):
     assert (ema - want1).abs().max().item() > 0.1
 
 
+def test_small_m_64_row_tiles_on_off(eng):
+    """option "conv_bm64" through the network: at batch 1, 416 x 416 the 52x52 / 26x26 / 13x13 layers run on 64-row tiles with their own
+    K-split plan (fewer slices): the head output agrees with the 128-row plan to fp32 rounding, each setting is bit-reproducible,
+    and the default (on) is the one the oracle tests above run."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand((1, 416, 416, 3), generator=g).cuda()
+    eng.init_synthetic(seed=7)
+    ys = {}
+    try:
+        for on in (1, 0):
+            eng.ctx.set_option('conv_bm64', on)
+            y = eng.predict_device(x).clone()
+            assert torch.equal(y, eng.predict_device(x))
+            ys[on] = y
+    finally:
+        eng.ctx.set_option('conv_bm64', 1)
+    assert (ys[1] - ys[0]).abs().max().item() <= 2e-5 * ys[0].abs().max().item()
+    assert not torch.equal(ys[1], ys[0])          # the plans really differ
+
+
 def test_workspace_too_small_is_reported(eng):
     import ctypes
     from face_vijnana_yolov3_amd._lib import lib, ptr

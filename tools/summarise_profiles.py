@@ -43,7 +43,7 @@ def main():
         line = bench_line(os.path.join(g, '%s_%s_bench.json' % (tag, mode)))
         json.dump(line, open(os.path.join(p, '%s_rocprofv3_bench_line_%s.json' % (out, mode)), 'w'), indent=1)
         for r in csv.DictReader(open(stats)):
-            if re.search(r'conv_kernel<128, 2, [24], false', r['Name']):
+            if re.search(r'conv_kernel<128, 2, [24], false|conv1x1_persist_kernel<128', r['Name']):
                 print(mode, 'rocprofv3 dominant kernel: calls', r['Calls'], 'avg us', float(r['AverageNs']) / 1e3,
                       '| bench avg_launch_ms', (line.get('roofline') or {}).get('avg_launch_ms'),
                       '| overlapped', (line.get('roofline_overlapped') or {}).get('avg_launch_ms'))
@@ -79,14 +79,14 @@ def main():
                                mfma_util=round(a.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (a['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0), 4))
         json.dump(util, open(os.path.join(p, '%s_pmc_mfma_util.json' % out), 'w'), indent=1)
         for k in util:
-            if re.match(r'conv_kernel<128, 2, [24], false', k) or k.startswith('wgrad_kernel<128, 128, true, false'):
+            if re.match(r'conv_kernel<128, 2, [24], false|conv1x1_persist_kernel<128', k) or k.startswith('wgrad_kernel<128, 128, true, false'):
                 print('MfmaUtil', k, util[k]['mfma_util'])
     traffic['_note'] = ('rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes over: bench.py --steps 1 '
                         '--warmup 1 --no-cpu-baseline --profile-steps 0 --no-overlap --no-detect; MB per launch; FETCH_SIZE '
                         'doubled (gfx950 correction); fabric-side requests, Infinity-Cache hits included')
     json.dump(traffic, open(os.path.join(p, '%s_pmc_traffic.json' % out), 'w'), indent=1)
     for k in traffic:
-        if re.match(r'conv_kernel<128, 2, [24], false', k) or k.startswith('wgrad_kernel<128, 128, true, false'):
+        if re.match(r'conv_kernel<128, 2, [24], false|conv1x1_persist_kernel<128', k) or k.startswith('wgrad_kernel<128, 128, true, false'):
             print(k, traffic[k])
 
 
