@@ -601,9 +601,14 @@ int fv_conv_choose_ksplit(int M, int Nout, int ksteps, bool allow_bm64) {
     const int bm = allow_bm64 && fv_conv_bm64(M, Nout, ksteps) ? 64 : BM;
     const int tiles = ((M + bm - 1) / bm) * ((Nout + bn - 1) / bn);
     if (tiles >= 192 || ksteps < 8) return 1;         // enough tiles to fill 256 CUs, or nothing to split
-    int want = (512 + tiles - 1) / tiles, cap = ksteps / 4;
+    // As many K slices as fit ONE round of the 512 resident workgroup slots (floor, not ceil: 86 tiles x 6 slices = 516 workgroups are
+    // two rounds -- tools/bs1_shapes.py, round 5: 29.1 us against 27.0 with 5 slices; 44 x 12 = 528: 29.2 against 24.8 with 10), at
+    // least four K steps per slice, no empty slice.
+    const int want = 512 / tiles, cap = ksteps / 4;
     int ks = want < cap ? want : cap;
-    return ks < 1 ? 1 : ks;
+    if (ks < 1) ks = 1;
+    const int per = (ksteps + ks - 1) / ks;
+    return (ksteps + per - 1) / per;
 }
 
 void fv_conv_tail_plan(int M, int Nout, int ksteps, int* tail_f, int* tail_full, long long* slab_floats) {

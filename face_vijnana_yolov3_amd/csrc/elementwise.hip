@@ -5,6 +5,7 @@
 // All tensors NHWC float32; 16-byte vector accesses; reductions in fixed order, except the BN accumulator
 // slots of the training step, which are filled with fp64 atomics (fp32 partials are exact in fp64; only
 // the order of the fp64 additions varies, far below fp32 resolution -- see DESIGN.md 4.3).
+#include <string>
 #include "elementwise.h"
 
 namespace {
@@ -785,7 +786,8 @@ int fv_ew_slice_cols(fv_ctx* ctx, const float* src, float* dst, long long rows, 
 
 int fv_ew_splitk_finish(fv_ctx* ctx, const float* slabs, int ksplit, long long stride, const float* scale, const float* shift,
                         const float* skip, float* out, long long n, int C, float leaky, int do_leaky) {
-    FvProfScope ps(ctx, "splitk_finish_kernel", 0.0, 4.0 * n * (ksplit + 1 + (skip ? 1 : 0)));
+    FvProfScope ps(ctx, "splitk_finish_kernel", "M" + std::to_string(n / C) + " N" + std::to_string(C) + " ks" + std::to_string(ksplit), 0.0,
+                   4.0 * n * (ksplit + 1 + (skip ? 1 : 0)));
     const bool al16 = (((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)skip | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0;
     if ((n & 3) == 0 && (stride & 3) == 0 && (C & 3) == 0 && al16) {
         hipLaunchKernelGGL(splitk_finish4_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, ctx->stream, (const float4*)slabs, ksplit, stride / 4,
