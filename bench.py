@@ -345,7 +345,7 @@ def test_loop_bench(device, S, n_img=256, head='single'):
     return dict(unit='images/sec', eval_batch_1=out['batch1'], eval_batch_16=out['batch16'], eval_batch_32=out['batch32'], images=n_img, csv_rows=rows,
                 loader_threads=default_threads, eval_batch_32_by_loader_threads=sweep, host_cpus=host_cpus(),
                 path='FaceDetector.test(): %d synthetic JPEGs (768x1024 .. 720x1280), Huffman decoding on hps.loader_threads host threads (default '
-                     'half the usable CPUs, 4 .. 32) into reused pinned buffers one batch ahead, fv_jpeg_reconstruct_batch, fv_letterbox_batch, '
+                     'the usable CPUs, 4 .. 32) into reused pinned buffers one batch ahead, fv_jpeg_reconstruct_batch, fv_letterbox_batch, '
                      'fv_forward_infer, fv_decode_nms, back-projection, csv' % n_img)
 
 

@@ -54,11 +54,11 @@ def effective_cpus():
 
 
 def default_loader_threads():
-    """hps['loader_threads'] when the configuration does not set it: half the CPUs the process may use, at least 4, at most 32
-    (the reference asks for 4 or 8 Keras workers, fd.py:621-627).  Measured (bench.py `test_loop`, eval batch 32, a 16-CPU share of
-    a 256-thread host): 8 / 16 / 32 / 64 threads -> 1913 / 1900 / 1874 / 1860 img/s -- beyond the quota more threads only add
-    switching; the loop is loader-bound there (loader alone 1964 img/s, the forward sustains 2500)."""
-    return max(4, min(32, effective_cpus() // 2))
+    """hps['loader_threads'] when the configuration does not set it: the CPUs the process may use, at least 4, at most 32 (the
+    reference asks for 4 or 8 Keras workers, fd.py:621-627).  Measured (bench.py `test_loop`, eval batch 32, a 16-CPU share of a
+    256-thread host): 8 / 16 / 32 / 64 threads -> 1990 / 2073 / 2058 / 2021 img/s -- flat beyond the quota; the loop is bound
+    by the device there (forward 0.40 ms/img = 2500 img/s, plus the JPEG reconstruction and letterbox kernels beside it)."""
+    return max(4, min(32, effective_cpus()))
 
 
 def map_all(pool, fn, items):
@@ -358,15 +358,44 @@ class FaceDetector(object):
                 for i, (name, boxes, geom) in enumerate(zip(chunk_, self._detect_collect(launched), geoms_)):
                     self._project_back(boxes, geom)
                     yield name, (raws_[i] if raws_ is not None else None), boxes
+            # The device half of the input path (H2D copy of the batch -- 70 MB of JPEG coefficients at 32 images: ~3 ms of PCIe time --,
+            # fv_jpeg_reconstruct_batch, fv_letterbox_batch) runs on its OWN stream: batch k+1 is staged while batch k's forward computes
+            # (on one stream the copy sat in front of every forward: 16.7 ms per batch of 32 where the forward takes 12.8).
+            import torch
+            dev = self.model.dev
+            main = torch.cuda.current_stream(dev)
+            if getattr(self, '_stage_stream', None) is None:
+                self._stage_stream = torch.cuda.Stream(device=dev)
+            side = self._stage_stream
+
+            def stage(loaded):
+                raws, packed = loaded
+                with torch.cuda.stream(side):
+                    self.model.ctx.set_stream(side.cuda_stream)
+                    try:
+                        x, geoms = letterbox_batch_device(self.model.ctx, raws, self.image_size, dev, packed=packed)
+                    finally:
+                        self.model.ctx.set_stream(main.cuda_stream)
+                    ring.copied(packed[1] if isinstance(packed[0], str) else packed[0])   # event on the staging stream: the pinned slot is free after it
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                return raws, geoms, x, ev
+
             prev = None
             pending = one.submit(load, chunks[0])
+            staged = stage(pending.result())
+            if len(chunks) > 1:
+                pending = one.submit(load, chunks[1])
             for k, chunk in enumerate(chunks):
-                raws, packed = pending.result()
-                if k + 1 < len(chunks):
-                    pending = one.submit(load, chunks[k + 1])
-                x, geoms = letterbox_batch_device(self.model.ctx, raws, self.image_size, self.model.dev, packed=packed)
-                ring.copied(packed[1] if isinstance(packed[0], str) else packed[0])       # the H2D copy of the buffer is in the queue
+                raws, geoms, x, ev = staged
+                main.wait_event(ev)
+                x.record_stream(main)              # allocated on the staging stream, consumed on the compute stream
                 cur = (chunk, raws, geoms, self._detect_launch(x))
+                if k + 1 < len(chunks):            # the host waits for the decode of k+1 while the GPU runs batch k, then stages it beside it
+                    loaded = pending.result()
+                    if k + 2 < len(chunks):
+                        pending = one.submit(load, chunks[k + 2])
+                    staged = stage(loaded)
                 if prev is not None:               # read batch k-1 now that batch k is in the queue
                     for item in finish(prev):
                         yield item
