@@ -173,3 +173,41 @@ def test_training_sequence_three_scale_contract(tmp_path):
     assert [y['output%d' % s].shape for s in range(3)] == [(2, 2, 2, 18), (2, 4, 4, 18), (2, 8, 8, 18)]
     raws, gts = seq.get_raw(1)
     assert len(raws) == 1 and [g.shape for g in gts] == [(1, 2, 2, 18), (1, 4, 4, 18), (1, 8, 8, 18)]
+
+
+def test_back_projection_on_arrays_equals_the_reference_expressions():
+    """FaceDetector._project_back evaluates fd.py:700-710 for all boxes of an image at once; the values AND the text str() makes
+    of them in the csv row must be the reference's per-box `np.min([...])` / `np.max([...])` expressions, bit for bit."""
+    from face_vijnana_yolov3_amd.face_detection import FaceDetector
+    from face_vijnana_yolov3_amd.postproc import BoundBox
+
+    class F:
+        image_size = 416
+    S = 416
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        h, w = [(768, 1024), (1024, 768), (600, 600), (333, 601), (1080, 1920)][trial % 5]
+        pad_t, pad_l = int(rng.integers(0, 120)), int(rng.integers(0, 120))
+        geom = (h, w, pad_t, 0, pad_l, 0)
+        coords = rng.integers(-30, 500, (int(rng.integers(0, 70)), 4))
+        boxes = [BoundBox(int(c[0]), int(c[1]), int(c[2]), int(c[3]), objness=0.5, classes=[0.7]) for c in coords]
+        FaceDetector._project_back(F, boxes, geom)
+        for b, c in zip(boxes, coords):
+            xmin, ymin, xmax, ymax = [int(v) for v in c]
+            if w >= h:
+                ref = (np.min([xmin * w / S, w]), np.min([np.max([ymin - pad_t, 0]) * w / S, h]),
+                       np.min([xmax * w / S, w]), np.min([np.max([ymax - pad_t, 0]) * w / S, h]))
+            else:
+                ref = (np.min([np.max([xmin - pad_l, 0]) * h / S, w]), np.min([ymin * h / S, h]),
+                       np.min([np.max([xmax - pad_l, 0]) * h / S, w]), np.min([ymax * h / S, h]))
+            got = (b.xmin, b.ymin, b.xmax, b.ymax)
+            assert got == ref and [str(g) for g in got] == [str(r) for r in ref]
+            assert str(b.xmax - b.xmin) == str(ref[2] - ref[0]) and str(b.ymax - b.ymin) == str(ref[3] - ref[1])
+
+
+def test_default_loader_threads_respects_affinity_and_quota():
+    from face_vijnana_yolov3_amd import face_detection as fdm
+    n = fdm.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or n)
+    assert 4 <= fdm.default_loader_threads() <= 32
+    assert fdm.default_loader_threads() == max(4, min(32, n))
