@@ -33,6 +33,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # before the HIP runtime initialises (face_vijnana_yolov3_amd/__init__.py says why); inherited by the ranks
 
 IMAGE_SIZE = 416
 PER_GPU_BATCH = 40

@@ -1,4 +1,4 @@
-"""Per-launch-shape breakdown of the base training step (416x416, batch 40) in the serial schedule: fv_profile_enable(ctx, 2)."""
+"""Per-launch-shape breakdown of the base training step in the serial schedule: fv_profile_enable(ctx, 2).  Usage: base_profile.py [batch=40] [image_size=416]"""
 import os, sys
 
 
@@ -9,8 +9,9 @@ def main():
     from face_vijnana_yolov3_amd import data
     from face_vijnana_yolov3_amd.engine import Engine
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 416
     eng = Engine(0); eng.init_synthetic(7)
-    x = torch.rand((B, 416, 416, 3)).cuda(); y = torch.from_numpy(data.synth_gt_batch(B, 416, seed=1)).cuda()
+    x = torch.rand((B, S, S, 3)).cuda(); y = torch.from_numpy(data.synth_gt_batch(B, S, seed=1)).cuda()
     for _ in range(3):
         eng.train_on_batch(x, y, **bench.HPS)
     eng.ctx.set_overlap(False)
