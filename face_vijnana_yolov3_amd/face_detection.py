@@ -43,11 +43,16 @@ def effective_cpus():
     """CPUs this process may really use: the affinity mask, cut by the cgroup CPU quota where one is set (a 1-GPU share of an
     MI355X host shows 256 logical CPUs and a quota of 16)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 8)
-    for path in ('/sys/fs/cgroup/cpu.max',):
-        try:
-            q, per = open(path).read().split()
-            if q != 'max':
-                n = min(n, max(1, int(int(q) / int(per))))
+    try:                                        # cgroup v2
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:                                    # cgroup v1
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, q // per))
         except (OSError, ValueError):
             pass
     return n
