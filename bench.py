@@ -9,10 +9,11 @@ A step = forward (training-mode BN) + MSE + backward + (N>1: RCCL all-reduce of 
 gradients, bucketed and overlapped with backward) + Keras-formula Adam, on synthetic inputs that
 are already resident in HBM.  Rank 0 prints ONE JSON line.
 
-`roofline`: the dominant kernel is the 128x128-tile fp32-MFMA implicit-GEMM conv
-(conv_kernel<128,2,4,false>, 8 waves per workgroup: forward and data-gradient of every layer with >= 128
-output channels; conv_kernel<128,2,2,false> under fv_set_option("conv_waves8", 0)).  achieved = algorithmic FLOPs of its launches / their HIP-event-timed duration, taken in
-instrumented steps right after the timed region (the timed steps themselves run un-instrumented).
+`roofline`: the dominant kernel FAMILY is the 128x128-tile fp32-MFMA implicit-GEMM conv -- forward and data-gradient of every layer
+with >= 128 output channels, 92 launches per step: conv_kernel<128,2,4,false> (8 waves per workgroup; <128,2,2,false> under option
+"conv_waves8" = 0) and, since round 5, conv1x1_persist_kernel<128> for its 1x1 launches with more than 512 tiles (the same tile, K loop
+and epilogue, persistent over tiles).  achieved = algorithmic FLOPs of the family's launches / their HIP-event-timed duration, taken in
+instrumented steps right after the timed region (the timed steps themselves run un-instrumented); `parts` gives each kernel name.
 peak = 157.3 TFLOP/s, the dense fp32 MFMA rate of MI355X (MI355X_MICROARCH.md).
 `cpu_baseline`: the torch-CPU oracle restatement of the same step (kind "port"; the Keras/TF
 reference cannot run here) on a bounded sample, timed on this box's host cores; `detect_cpu` inside it is
