@@ -261,7 +261,8 @@ static int forward_impl(fv_ctx* ctx, const float* params, const float* bn_state,
         float* out = (feat && l == nb - 1) ? feat : p.G[iout];
         const float* w = l == 0 ? p.w0p : params + d.w_off;
         const long long rows = (long long)batch * (H / d.stride) * (H / d.stride);
-        const int ks = l == 0 ? 1 : fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32, ctx->conv_bm64);
+        const int ks = l == 0 ? 1 : (ctx->conv1x1_small && d.ksize == 1 && fv_conv1x1_small_ok((int)rows, d.cout, d.cin)) ? 1
+                       : fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32, ctx->conv_bm64);
         if (ks > 1) {
             // small M (batch-1 latency): K-split partial slabs, summed in fixed order by the finish kernel
             if (int rc = fv_op_conv_forward(ctx, cur, w, batch, H, H, d.cin, d.cout, d.ksize, d.stride, 0, nullptr, nullptr, 0.f,

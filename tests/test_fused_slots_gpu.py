@@ -455,7 +455,7 @@ def test_unknown_option_is_refused(ctx):
         ctx.set_option('no_such_switch', 1)
     with pytest.raises(FvError):
         ctx.get_option('no_such_switch')
-    for key in ('overlap', 'tail_split', 'conv_waves8', 'conv1x1_persist', 'conv_bm64', 'conv_halo', 'conv0_direct', 'wgrad_fused_taps'):
+    for key in ('overlap', 'tail_split', 'conv_waves8', 'conv1x1_persist', 'conv_bm64', 'conv1x1_small', 'conv_halo', 'conv0_direct', 'wgrad_fused_taps'):
         assert ctx.get_option(key) == 1
         ctx.set_option(key, 0); assert ctx.get_option(key) == 0
         ctx.set_option(key, 1)
@@ -486,3 +486,34 @@ def test_64_row_tiles_equal_128_row_tiles(ctx, B, H, cin, cout, k, s):
     tol = 2e-6 * bound * scale.cpu().double().abs() + 1e-5
     # (elements within rounding of the LeakyReLU kink may take the other slope in float32: bounded by the same tolerance x 1)
     assert ((res[True].cpu().double() - want).abs() <= tol + 0.9 * (pre.abs() <= tol).double() * pre.abs()).all()
+
+
+@pytest.mark.parametrize('B,H,cin,cout', [(1, 52, 256, 128), (1, 26, 512, 256), (1, 13, 1024, 512), (3, 13, 1024, 512), (1, 26, 768, 256),
+                                          (1, 52, 384, 128), (1, 13, 128, 64), (2, 7, 512, 1024)])
+def test_small_m_1x1_conv_with_the_k_split_inside_the_workgroup(ctx, B, H, cin, cout):
+    """option "conv1x1_small" (conv1x1_small_kernel): small-M 1x1 inference launches, K in four quarters multiplied by the four wave
+    pairs of a workgroup and added in pair order.  Right against float64 (the operator bound), bit-reproducible, and within fp32
+    rounding of the unsplit tile kernels (another summation order); ragged M (169, 507, 49 x 2 rows), K of 4 ... 32 steps."""
+    from face_vijnana_yolov3_amd import ops
+    x = _rand((B, H, H, cin), 511).cuda(); w = _rand((cout, 1, 1, cin), 512, -0.2, 0.2).cuda()
+    scale = _rand((cout,), 513, 0.5, 1.5).cuda(); shift = _rand((cout,), 514).cuda(); add = _rand((B, H, H, cout), 515).cuda()
+    res = {}
+    try:
+        for on in (1, 0):
+            ctx.set_option('conv1x1_small', on)
+            y = ops.conv2d_forward(ctx, x, w, 1, scale, shift, 0.1, add)
+            y2 = ops.conv2d_forward(ctx, x, w, 1, scale, shift, 0.1, add)
+            plain = ops.conv2d_forward(ctx, x, w, 1)
+            torch.cuda.synchronize()
+            assert torch.equal(y, y2)
+            res[on] = (y, plain)
+    finally:
+        ctx.set_option('conv1x1_small', 1)
+    ref = _ref_conv(x.cpu().double(), w.cpu().double(), 1, 1); bound = _ref_conv(x.cpu().double().abs(), w.cpu().double().abs(), 1, 1)
+    for on in (1, 0):
+        assert ((res[on][1].cpu().double() - ref).abs() <= 2e-6 * bound + 1e-6).all(), on
+    assert not torch.equal(res[1][1], res[0][1])            # the new kernel really ran (another summation order)
+    pre = ref * scale.cpu().double() + shift.cpu().double()
+    want = torch.where(pre > 0, pre, 0.1 * pre) + add.cpu().double()
+    tol = 2e-6 * bound * scale.cpu().double().abs() + 1e-5
+    assert ((res[1][0].cpu().double() - want).abs() <= tol + 0.9 * (pre.abs() <= tol).double() * pre.abs()).all()
