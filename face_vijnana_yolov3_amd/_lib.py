@@ -151,7 +151,7 @@ class Context:
 
     def set_option(self, key, value):
         """fv_set_option: a tuning switch of include/fv_hotpath.h ('overlap', 'tail_split', 'conv_waves8', 'conv1x1_persist',
-        'conv_bm64', 'conv1x1_small', 'conv_halo', 'conv0_direct', 'wgrad_fused_taps')."""
+        'conv_bm64', 'conv_small', 'conv_halo', 'conv0_direct', 'wgrad_fused_taps')."""
         self.check(lib().fv_set_option(self._h, key.encode(), int(value)), 'fv_set_option(%s)' % key)
 
     def get_option(self, key):

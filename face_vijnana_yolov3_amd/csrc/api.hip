@@ -69,7 +69,7 @@ const FvOption kOptions[] = {
     {"conv_waves8", &fv_ctx::conv_waves8},
     {"conv1x1_persist", &fv_ctx::conv1x1_persist},
     {"conv_bm64", &fv_ctx::conv_bm64},
-    {"conv1x1_small", &fv_ctx::conv1x1_small},
+    {"conv_small", &fv_ctx::conv_small},
     {"conv_halo", &fv_ctx::conv_halo},
     {"conv0_direct", &fv_ctx::conv0_direct},
     {"wgrad_fused_taps", &fv_ctx::wgrad_fused_taps},

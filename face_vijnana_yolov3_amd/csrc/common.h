@@ -37,7 +37,7 @@ struct fv_ctx {
     long long bn_ema_step = 0;   // fv_set_bn_zero_debias_step: 0 plain EMA of the BN moving statistics, t >= 1 Keras 2.2.4's zero-debiased update t
     bool wgrad_fused_taps = true;   // option "wgrad_fused_taps": wgrad9_mfma.hip for the 32 -> 64 channel 3x3 layers
     bool conv_halo = true;      // option "conv_halo": conv9_mfma.hip (training forward) and dgrad9s2_mfma.hip (stride-2 data-gradient) for the 32 -> 64 channel 3x3 layers
-    bool conv1x1_small = true;   // option "conv1x1_small": conv1x1_small_kernel for small-M 1x1 inference launches (fv_conv1x1_small_ok)
+    bool conv_small = true;      // option "conv_small": conv_small_kernel for small-M inference launches (fv_conv_small_plan)
     bool conv_bm64 = true;       // option "conv_bm64": 64-row tiles for small-M inference launches (fv_conv_bm64)
     bool conv1x1_persist = true; // option "conv1x1_persist": conv1x1_mfma.hip for 1x1 launches with more than 512 tiles
     bool conv0_direct = true;    // option "conv0_direct": vector-FMA first layer (conv0_direct.hip) instead of the gather kernel

@@ -48,7 +48,7 @@ struct FvConvArgs {
     int tail_full;
     float* tail_slab;  // [tail tiles * tail_f][128][BN] raw partial tiles
     int bm64;          // 1: 64-row tiles (fv_conv_bm64: small-M inference launches with 128-wide tiles)
-    int small1x1;      // 1: conv1x1_small_kernel (small-M 1x1 inference launch, K split four ways inside the workgroup)
+    int small;         // 1..3: conv_small_kernel configuration (small-M inference launch, K split inside the workgroup; fv_conv_small_plan)
     int narrow;        // 1: 128x32 tiles whatever Nout (small-M 1x1 layers of the inference path, fv_conv_narrow)
     int ksplit;        // >1: blockIdx.y owns a slice of the K steps and stores its raw partial to out + y*split_stride
     long long split_stride;
@@ -78,9 +78,9 @@ int fv_dgrad9s2_launch(fv_ctx* ctx, const FvConvArgs& a);
 // conv1x1_mfma.hip: 1x1 stride-1 launches with more tiles than resident workgroup slots as a persistent GEMM (bit-identical)
 bool fv_conv1x1_persist_ok(const FvConvArgs& a);
 int fv_conv1x1_persist_launch(fv_ctx* ctx, const FvConvArgs& a);
-// conv1x1_mfma.hip: small-M 1x1 inference launches (batch 1) with the K split inside the workgroup
-bool fv_conv1x1_small_ok(int M, int Nout, int Cin);
-int fv_conv1x1_small_launch(fv_ctx* ctx, const FvConvArgs& a);
+// conv_small_mfma.hip: small-M inference launches (batch 1) with the K split inside the workgroup; plan: 0 = not taken, 1..3 = configuration
+int fv_conv_small_plan(int M, int Nout, int Cin, int ntaps);
+int fv_conv_small_launch(fv_ctx* ctx, const FvConvArgs& a);
 // conv0_direct.hip: the 3 -> 32 channel first layer as a direct vector-FMA convolution (bit-identical to the gather kernel)
 bool fv_conv0_direct_ok(const FvConvArgs& a);
 int fv_conv0_direct_launch(fv_ctx* ctx, const FvConvArgs& a);

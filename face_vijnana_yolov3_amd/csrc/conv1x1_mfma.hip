@@ -263,131 +263,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4) void conv1x1_persist_ker
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Small-M 1x1 convolution (batch-1 inference: 52x52 / 26x26 / 13x13 pixels): K split FOUR WAYS INSIDE the workgroup.
-// At batch 1 a 1x1 layer is ~0.2 GFLOP -- a microsecond of matrix time -- and its launch lasts as long as ONE workgroup's chain of
-// dependent K steps (global load -> LDS -> MFMA, ~1 us each): the 128 x 32-tile launches ran 16 steps = 18.7 us (26x26), 8 steps =
-// 13.6 us (52x52) on 48 / 88 workgroups (tools/bs1_shapes.py).  Splitting K over more workgroups needs a finish launch that costs
-// what it saves.  Here a 512-thread workgroup owns a 64 x 32 output tile and its four wave pairs each multiply ONE QUARTER of K
-// (own double-buffered operand tiles in LDS, all four quarters' loads in flight at once), then pairs 1-3 hand their 32 x 32
-// accumulators through LDS to pair 0's layout and the sums are formed in pair order (q0 + q1 + q2 + q3: deterministic), followed
-// by the inference epilogue (affine, LeakyReLU, residual).  The dependent chain is a quarter as long: 4 / 2 / 8 steps.
-// One workgroup per CU (110 KB of LDS), launches of at most 256 workgroups only.
-constexpr int SM_BM = 64, SM_BN = 32, SM_Q = 4;
-constexpr int SM_GROUP_FLOATS = 2 * (SM_BM + SM_BN) * LDT;           // one pair's double-buffered A + B tiles
-
-// PF: K steps whose operand rows a thread requests before it multiplies anything (all of a quarter's steps up to four: the launch is
-// a chain of memory latencies otherwise -- 6 x 16 B per thread and step, 24 VGPRs; two waves per SIMD leave 256).
-template <int PF>
-__global__ __launch_bounds__(512, 2) void conv1x1_small_kernel(const FvConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[SM_Q * SM_GROUP_FLOATS];
-    static_assert(SM_Q * SM_GROUP_FLOATS >= (SM_Q - 1) * SM_BM * SM_BN + SM_BM * SM_BN, "the operand LDS must hold the hand-off tiles");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = wave >> 1, wr = wave & 1;                 // K quarter of this wave pair; which 32 rows of the tile this wave owns
-    const int gt = tid & 127;                                // thread index inside the pair
-    const int NT = a.Nout / SM_BN;
-    const int mt = blockIdx.x / NT, nt = blockIdx.x - mt * NT;
-    const int m0 = mt * SM_BM, n0 = nt * SM_BN;
-    const int nk = a.Cin / BK, per = nk / SM_Q;              // K steps per quarter (nk % 4 == 0: fv_conv1x1_small_ok)
-    float* As0 = smem + q * SM_GROUP_FLOATS;                 // [2][64][LDT]
-    float* Bs0 = As0 + 2 * SM_BM * LDT;                      // [2][32][LDT]
-
-    constexpr unsigned OOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((unsigned)a.M * a.Cin * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((unsigned)a.Nout * a.Cin * 4u), 0x00020000);
-    const int col4 = (gt & 7) * 4, r0 = gt >> 3;             // 16 rows per pass of the pair's 128 threads
-    unsigned a_off[4], b_off[2];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int m = m0 + r0 + 16 * p;
-        a_off[p] = m < a.M ? (unsigned)(m * a.Cin + col4) * 4u : OOB;
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) b_off[p] = (unsigned)((n0 + r0 + 16 * p) * a.Cin + col4) * 4u;      // Nout % 32 == 0: always in range
-    u32x4 ra[PF][4], rb[PF][2];
-    auto load = [&](int slot, int s) {                        // K step s of THIS quarter into register slot `slot`
-        const int c0b = (q * per + s) * BK * 4;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) ra[slot][p] = __builtin_amdgcn_raw_buffer_load_b128(xr, a_off[p], c0b, 0);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) rb[slot][p] = __builtin_amdgcn_raw_buffer_load_b128(wr_, b_off[p], c0b, 0);
-    };
-    auto stage = [&](int buf, int slot) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(&As0[buf * SM_BM * LDT + (r0 + 16 * p) * LDT + col4]) = ra[slot][p];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(&Bs0[buf * SM_BN * LDT + (r0 + 16 * p) * LDT + col4]) = rb[slot][p];
-    };
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const int arow = (wr * 32 + (lane & 31)) * LDT + (lane >> 5) * 4;
-    const int brow = (lane & 31) * LDT + (lane >> 5) * 4;
-    auto compute = [&](int cur) {
-        const float* Ac = As0 + cur * SM_BM * LDT; const float* Bc = Bs0 + cur * SM_BN * LDT;
-#pragma unroll
-        for (int kc = 0; kc < BK / 8; ++kc) {                 // the chunk / lane-half k order of conv_kernel
-            const float4 af = *reinterpret_cast<const float4*>(&Ac[arow + kc * 8]);
-            const float4 bf = *reinterpret_cast<const float4*>(&Bc[brow + kc * 8]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
-        }
-    };
-
-    // rounds of PF steps: all PF steps' rows are requested first, then staged and multiplied one after the other (double-buffered
-    // LDS: step j is staged while step j - 1 is being read by the slower waves of the pair)
-    for (int s0 = 0; s0 < per; s0 += PF) {
-#pragma unroll
-        for (int j = 0; j < PF; ++j) load(j, s0 + j);         // (per % PF == 0: the launcher picks PF)
-#pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            stage(j & 1, j);
-            __syncthreads();
-            compute(j & 1);
-        }
-        __syncthreads();                                      // both buffers free again before the next round stages into them
-    }
-    // hand-off: quarters 1..3 park their accumulators, tile-local [64][32]; quarter 0 adds them in quarter order
-    const int half = lane >> 5, lc = lane & 31;
-    float* H = smem;                                          // [3][64][32] parked tiles, then [64][32] the sum
-    if (q > 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) H[(q - 1) * SM_BM * SM_BN + (wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * SM_BN + lc] = acc[r];
-    }
-    __syncthreads();
-    float* Cs = smem + (SM_Q - 1) * SM_BM * SM_BN;
-    if (q == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int e = (wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * SM_BN + lc;
-            float v = acc[r];
-#pragma unroll
-            for (int g = 0; g < SM_Q - 1; ++g) v += H[g * SM_BM * SM_BN + e];
-            Cs[e] = v;
-        }
-    }
-    __syncthreads();
-    // epilogue: 64 x 32 tile = 512 float4 pieces, one per thread
-    const int row = tid >> 3, c4 = (tid & 7) * 4;
-    const int m = m0 + row, n = n0 + c4;
-    if (m < a.M) {
-        float4 v = *reinterpret_cast<const float4*>(&Cs[row * SM_BN + c4]);
-        if (a.epi & FV_EPI_AFFINE) {
-            if (a.scale) { const float4 sc = *reinterpret_cast<const float4*>(a.scale + n); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
-            if (a.shift) { const float4 sh = *reinterpret_cast<const float4*>(a.shift + n); v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w; }
-        }
-        if (a.epi & FV_EPI_LEAKY) {
-            v.x = v.x > 0.f ? v.x : v.x * a.leaky; v.y = v.y > 0.f ? v.y : v.y * a.leaky;
-            v.z = v.z > 0.f ? v.z : v.z * a.leaky; v.w = v.w > 0.f ? v.w : v.w * a.leaky;
-        }
-        const size_t off = (size_t)m * a.Nout + n;
-        if (a.epi & FV_EPI_ADD) { const float4 sk = *reinterpret_cast<const float4*>(a.addend + off); v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w; }
-        *reinterpret_cast<float4*>(a.out + off) = v;
-    }
-}
-
 template <int BN, int WM_, int WN_>
 int launch_persist(fv_ctx* ctx, const FvConvArgs& a) {
     const bool bnred = (a.epi & FV_EPI_BNRED) != 0;
@@ -420,23 +295,4 @@ bool fv_conv1x1_persist_ok(const FvConvArgs& a) {
 int fv_conv1x1_persist_launch(fv_ctx* ctx, const FvConvArgs& a) {
     if (a.Nout > 64) return launch_persist<128, 2, 4>(ctx, a);
     return launch_persist<64, 4, 2>(ctx, a);
-}
-
-// Small-M 1x1 inference launch: K a multiple of 128 (four quarters of whole K steps), output channels a multiple of 32, no statistics /
-// BN-reduction epilogue, and at most 256 workgroups of 64 x 32 (one per CU: a second round would double the launch).
-bool fv_conv1x1_small_ok(int M, int Nout, int Cin) {
-    if (Cin % (SM_Q * BK) != 0 || Nout % SM_BN != 0 || M < 1) return false;
-    return (long long)((M + SM_BM - 1) / SM_BM) * (Nout / SM_BN) <= 256;
-}
-
-int fv_conv1x1_small_launch(fv_ctx* ctx, const FvConvArgs& a) {
-    const int grid = ((a.M + SM_BM - 1) / SM_BM) * (a.Nout / SM_BN);
-    FvProfScope ps(ctx, "conv1x1_small_kernel", "M" + std::to_string(a.M) + " N" + std::to_string(a.Nout) + " K" + std::to_string(a.Cin), a.alg_flops,
-                   4.0 * ((double)a.M * a.Cin + (double)a.Nout * a.Cin + (double)a.M * a.Nout * ((a.epi & FV_EPI_ADD) ? 2 : 1)));
-    const int per = a.Cin / BK / SM_Q;
-    if (per % 4 == 0) hipLaunchKernelGGL(conv1x1_small_kernel<4>, dim3(grid), dim3(512), 0, ctx->stream, a);
-    else if (per % 2 == 0) hipLaunchKernelGGL(conv1x1_small_kernel<2>, dim3(grid), dim3(512), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(conv1x1_small_kernel<1>, dim3(grid), dim3(512), 0, ctx->stream, a);
-    FV_LAUNCH_CHECK(ctx);
-    return FV_OK;
 }

@@ -693,7 +693,7 @@ int fv_conv_launch(fv_ctx* ctx, const FvConvArgs& a) {
     }
     for (int c = 0; c < a.nclass; ++c)
         FV_REQUIRE(ctx, a.taps[c].n >= 1 && a.taps[c].n <= 9, "conv: bad tap count");
-    if (a.small1x1) return fv_conv1x1_small_launch(ctx, a);
+    if (a.small) return fv_conv_small_launch(ctx, a);
     if (a.narrow) return launch_cfg<32, 4, 1, false>(ctx, a);
     if (ctx->conv1x1_persist && fv_conv1x1_persist_ok(a)) return fv_conv1x1_persist_launch(ctx, a);
     // 128-wide tiles: 8 waves (2 x 4, each 64 x 32) put four waves on every SIMD instead of two: the same per-element fmaf

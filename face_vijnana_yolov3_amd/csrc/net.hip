@@ -261,7 +261,7 @@ static int forward_impl(fv_ctx* ctx, const float* params, const float* bn_state,
         float* out = (feat && l == nb - 1) ? feat : p.G[iout];
         const float* w = l == 0 ? p.w0p : params + d.w_off;
         const long long rows = (long long)batch * (H / d.stride) * (H / d.stride);
-        const int ks = l == 0 ? 1 : (ctx->conv1x1_small && d.ksize == 1 && fv_conv1x1_small_ok((int)rows, d.cout, d.cin)) ? 1
+        const int ks = l == 0 ? 1 : (ctx->conv_small && d.cin % 32 == 0 && fv_conv_small_plan((int)rows, d.cout, d.cin, d.ksize * d.ksize)) ? 1
                        : fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32, ctx->conv_bm64);
         if (ks > 1) {
             // small M (batch-1 latency): K-split partial slabs, summed in fixed order by the finish kernel

@@ -255,7 +255,7 @@ int fv_yolov3_forward(fv_ctx* ctx, const float* params, const float* bn_state, c
         const float* w = d.darknet_index == 0 ? p.w0p : params + d.w_off;
         const float* sc = d.has_bn ? p.scale + d.mean_off / 2 : nullptr;
         const float* sh = d.has_bn ? p.shift + d.mean_off / 2 : params + d.beta_off;
-        const int ks = d.darknet_index == 0 ? 1 : (ctx->conv1x1_small && d.ksize == 1 && fv_conv1x1_small_ok((int)rows, d.cout, d.cin)) ? 1
+        const int ks = d.darknet_index == 0 ? 1 : (ctx->conv_small && d.cin % 32 == 0 && fv_conv_small_plan((int)rows, d.cout, d.cin, d.ksize * d.ksize)) ? 1
                        : fv_conv_choose_ksplit((int)rows, d.cout, d.ksize * d.ksize * d.cin / 32, ctx->conv_bm64);
         if (ks > 1) {
             if (int rc = fv_op_conv_forward(ctx, in, w, batch, H, H, d.cin, d.cout, d.ksize, d.stride, 0, nullptr, nullptr, 0.f, nullptr,

@@ -28,9 +28,9 @@ int fv_op_conv_forward(fv_ctx* ctx, const float* x, const float* w, int B, int H
     a.ksplit = ksplit; a.split_stride = (long long)a.M * cout;
     a.stat_slots = stat_slots; a.stat_nslot = stat_nslot;
     // inference epilogues only: the training forward keeps one tiling whatever the batch (its statistics are per-tile sums)
-    a.small1x1 = (ctx->conv1x1_small && ksize == 1 && stride == 1 && ksplit <= 1 && !(epi & FV_EPI_STATS) && fv_conv1x1_small_ok(a.M, cout, cin)) ? 1 : 0;
-    a.narrow = (!a.small1x1 && ksize == 1 && ksplit <= 1 && !(epi & FV_EPI_STATS) && cin % 32 == 0 && fv_conv_narrow(a.M, cout, cin / 32)) ? 1 : 0;
-    a.bm64 = (ctx->conv_bm64 && !a.narrow && !(epi & FV_EPI_STATS) && cin % 32 == 0 && fv_conv_bm64(a.M, cout, ksize * ksize * cin / 32)) ? 1 : 0;
+    a.small = (ctx->conv_small && ksplit <= 1 && !(epi & FV_EPI_STATS) && cin % 32 == 0) ? fv_conv_small_plan(a.M, cout, cin, ksize * ksize) : 0;
+    a.narrow = (!a.small && ksize == 1 && ksplit <= 1 && !(epi & FV_EPI_STATS) && cin % 32 == 0 && fv_conv_narrow(a.M, cout, cin / 32)) ? 1 : 0;
+    a.bm64 = (ctx->conv_bm64 && !a.small && !a.narrow && !(epi & FV_EPI_STATS) && cin % 32 == 0 && fv_conv_bm64(a.M, cout, ksize * ksize * cin / 32)) ? 1 : 0;
     return fv_conv_launch(ctx, a);
 }
 

@@ -75,9 +75,10 @@ int fv_set_bn_zero_debias_step(fv_ctx* ctx, long long step);
  *   "conv1x1_persist"   1x1 stride-1 launches with more than 512 tiles (forward and data-gradient of the 1x1 layers at batch >= ~16)
  *                       run as a persistent GEMM whose workgroups walk several tiles with the next tile's operands in flight
  *                       during the epilogue (conv1x1_mfma.hip) instead of one workgroup per tile.  Bit-identical.
- *   "conv1x1_small"     small-M inference (batch 1): a 1x1 layer whose 64 x 32-tile launch has at most 256 workgroups runs with the K
- *                       dimension split four ways INSIDE each 512-thread workgroup (four wave pairs, sums formed in pair order) instead
- *                       of a chain of 8 - 32 dependent K steps per workgroup.  Deterministic; another fp32 summation order.
+ *   "conv_small"        small-M inference (batch 1): a layer whose launch fits one workgroup per CU (<= 256 tiles of 64 x 64, 64 x 32
+ *                       or 32 x 32) runs with the K dimension split INSIDE each 512-thread workgroup (four wave pairs or eight waves
+ *                       multiply 1/4 or 1/8 of the K steps each, the sums are formed in group order) instead of K slices of one
+ *                       workgroup each + a finish launch.  Deterministic; another fp32 summation order.
  *   "conv_bm64"         small-M inference (fewer than 192 tiles of 128 x 128: batch 1): 64-row tiles where they leave fewer padded rows
  *                       than 128-row ones (13x13, 26x26, 52x52 pixels) -- less padding to multiply, fewer K slices to sum.  Changes the
  *                       K-split plan of those launches, i.e. their fp32 summation order.

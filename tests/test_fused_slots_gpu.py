@@ -455,7 +455,7 @@ def test_unknown_option_is_refused(ctx):
         ctx.set_option('no_such_switch', 1)
     with pytest.raises(FvError):
         ctx.get_option('no_such_switch')
-    for key in ('overlap', 'tail_split', 'conv_waves8', 'conv1x1_persist', 'conv_bm64', 'conv1x1_small', 'conv_halo', 'conv0_direct', 'wgrad_fused_taps'):
+    for key in ('overlap', 'tail_split', 'conv_waves8', 'conv1x1_persist', 'conv_bm64', 'conv_small', 'conv_halo', 'conv0_direct', 'wgrad_fused_taps'):
         assert ctx.get_option(key) == 1
         ctx.set_option(key, 0); assert ctx.get_option(key) == 0
         ctx.set_option(key, 1)
@@ -488,28 +488,38 @@ def test_64_row_tiles_equal_128_row_tiles(ctx, B, H, cin, cout, k, s):
     assert ((res[True].cpu().double() - want).abs() <= tol + 0.9 * (pre.abs() <= tol).double() * pre.abs()).all()
 
 
-@pytest.mark.parametrize('B,H,cin,cout', [(1, 52, 256, 128), (1, 26, 512, 256), (1, 13, 1024, 512), (3, 13, 1024, 512), (1, 26, 768, 256),
-                                          (1, 52, 384, 128), (1, 13, 128, 64), (2, 7, 512, 1024)])
-def test_small_m_1x1_conv_with_the_k_split_inside_the_workgroup(ctx, B, H, cin, cout):
-    """option "conv1x1_small" (conv1x1_small_kernel): small-M 1x1 inference launches, K in four quarters multiplied by the four wave
-    pairs of a workgroup and added in pair order.  Right against float64 (the operator bound), bit-reproducible, and within fp32
-    rounding of the unsplit tile kernels (another summation order); ragged M (169, 507, 49 x 2 rows), K of 4 ... 32 steps."""
+SMALL_CASES = [
+    # B, H, cin, cout, k, s
+    (1, 52, 256, 128, 1, 1), (1, 26, 512, 256, 1, 1), (1, 13, 1024, 512, 1, 1), (1, 26, 768, 256, 1, 1), (1, 52, 384, 128, 1, 1),   # 1x1 layers
+    (1, 104, 128, 64, 1, 1),                                                            # 64 x 64 tiles, one K step per group
+    (1, 52, 128, 256, 3, 2), (1, 26, 256, 512, 3, 2),                                   # the stride-2 3x3 layers into 26x26 and 13x13
+    (1, 30, 128, 256, 3, 2), (2, 13, 128, 128, 3, 1), (1, 9, 128, 512, 3, 1),           # ragged tiles (225, 338, 81 rows), stride-1 3x3 with a short K
+    (3, 7, 512, 1024, 1, 1),
+]
+
+
+@pytest.mark.parametrize('B,H,cin,cout,k,s', SMALL_CASES)
+def test_small_m_conv_with_the_k_split_inside_the_workgroup(ctx, B, H, cin, cout, k, s):
+    """option "conv_small" (conv_small_mfma.hip): small-M inference launches, the K steps divided over the four wave pairs / eight waves
+    of a workgroup and added in group order.  Right against float64 (the operator bound), bit-reproducible, within fp32 rounding of
+    the tile kernels (another summation order), for 1x1 and 3x3, stride 1 and 2, ragged M, every tile configuration."""
     from face_vijnana_yolov3_amd import ops
-    x = _rand((B, H, H, cin), 511).cuda(); w = _rand((cout, 1, 1, cin), 512, -0.2, 0.2).cuda()
-    scale = _rand((cout,), 513, 0.5, 1.5).cuda(); shift = _rand((cout,), 514).cuda(); add = _rand((B, H, H, cout), 515).cuda()
+    Ho = H // s
+    x = _rand((B, H, H, cin), 511).cuda(); w = _rand((cout, k, k, cin), 512, -0.2, 0.2).cuda()
+    scale = _rand((cout,), 513, 0.5, 1.5).cuda(); shift = _rand((cout,), 514).cuda(); add = _rand((B, Ho, Ho, cout), 515).cuda()
     res = {}
     try:
         for on in (1, 0):
-            ctx.set_option('conv1x1_small', on)
-            y = ops.conv2d_forward(ctx, x, w, 1, scale, shift, 0.1, add)
-            y2 = ops.conv2d_forward(ctx, x, w, 1, scale, shift, 0.1, add)
-            plain = ops.conv2d_forward(ctx, x, w, 1)
+            ctx.set_option('conv_small', on)
+            y = ops.conv2d_forward(ctx, x, w, s, scale, shift, 0.1, add)
+            y2 = ops.conv2d_forward(ctx, x, w, s, scale, shift, 0.1, add)
+            plain = ops.conv2d_forward(ctx, x, w, s)
             torch.cuda.synchronize()
             assert torch.equal(y, y2)
             res[on] = (y, plain)
     finally:
-        ctx.set_option('conv1x1_small', 1)
-    ref = _ref_conv(x.cpu().double(), w.cpu().double(), 1, 1); bound = _ref_conv(x.cpu().double().abs(), w.cpu().double().abs(), 1, 1)
+        ctx.set_option('conv_small', 1)
+    ref = _ref_conv(x.cpu().double(), w.cpu().double(), k, s); bound = _ref_conv(x.cpu().double().abs(), w.cpu().double().abs(), k, s)
     for on in (1, 0):
         assert ((res[on][1].cpu().double() - ref).abs() <= 2e-6 * bound + 1e-6).all(), on
     assert not torch.equal(res[1][1], res[0][1])            # the new kernel really ran (another summation order)

@@ -269,15 +269,35 @@ def test_small_m_64_row_tiles_on_off(eng):
     eng.init_synthetic(seed=7)
     ys = {}
     try:
+        eng.ctx.set_option('conv_small', 0)          # (with it on, most of these layers never reach the K-split path)
         for on in (1, 0):
             eng.ctx.set_option('conv_bm64', on)
             y = eng.predict_device(x).clone()
             assert torch.equal(y, eng.predict_device(x))
             ys[on] = y
     finally:
-        eng.ctx.set_option('conv_bm64', 1)
+        eng.ctx.set_option('conv_bm64', 1); eng.ctx.set_option('conv_small', 1)
     assert (ys[1] - ys[0]).abs().max().item() <= 2e-5 * ys[0].abs().max().item()
     assert not torch.equal(ys[1], ys[0])          # the plans really differ
+
+
+def test_small_m_kernel_on_off_through_the_network(eng):
+    """option "conv_small" through the network at batch 1 (416 and 608) and batch 2: the head output agrees with the K-split tile
+    path to fp32 rounding; each setting is bit-reproducible."""
+    eng.init_synthetic(seed=7)
+    for B, S in ((1, 416), (1, 608), (2, 416)):
+        x = torch.rand((B, S, S, 3), generator=torch.Generator().manual_seed(78 + S)).cuda()
+        ys = {}
+        try:
+            for on in (1, 0):
+                eng.ctx.set_option('conv_small', on)
+                y = eng.predict_device(x).clone()
+                assert torch.equal(y, eng.predict_device(x))
+                ys[on] = y
+        finally:
+            eng.ctx.set_option('conv_small', 1)
+        assert (ys[1] - ys[0]).abs().max().item() <= 2e-5 * ys[0].abs().max().item(), (B, S)
+        assert not torch.equal(ys[1], ys[0]), (B, S)
 
 
 def test_workspace_too_small_is_reported(eng):
