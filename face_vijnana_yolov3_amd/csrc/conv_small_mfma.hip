@@ -24,35 +24,45 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const FvConvArgs a) 
     constexpr int WQ = 8 / Q;                    // waves per K group: each owns 32 rows of the tile
     static_assert(TM == 32 * WQ && (TN == 32 || TN == 64) && (Q == 4 || Q == 8), "bad small-M tiling");
     constexpr int NBK = TN / 32;                 // 32 x 32 accumulator blocks per wave
-    constexpr int GT = 64 * WQ;                  // threads per group
-    constexpr int RS = GT / 8;                   // tile rows covered by one pass of a group's threads (8 threads x 16 B = one 32-float row)
-    constexpr int APT = TM / RS, BPT = TN / RS;  // float4 loads per thread and K step: A always 4, B 2 or 4
-    constexpr int GF = 2 * (TM + TN) * LDT;      // one group's double-buffered A + B tiles (floats)
-    __shared__ __attribute__((aligned(16))) float smem[Q * GF];
-    static_assert(Q * GF >= Q * TM * TN, "the operand LDS must hold the parked accumulator tiles and their sum");
-    static_assert(Q * GF * 4 <= 160 * 1024, "LDS");
+    // Staging unit = the waves that share one set of operand tiles in LDS.  TN = 32: every WAVE has its own (its 32 A rows + a private
+    // copy of the 32 B rows: 18 KB, 147 KB per workgroup) -- nothing in the K loop is shared between waves, so it contains NO barrier
+    // and the eight waves run free (the shared form synchronised all eight at every step although only a pair shares tiles: 1.65 us
+    // per step for 0.85 us of matrix time).  TN = 64: a K group's two waves share their tiles (a private B copy would not fit) and
+    // keep the workgroup barrier per step.
+    constexpr bool PRIV = TN == 32;
+    constexpr int SW = PRIV ? 1 : WQ;            // waves per staging unit
+    constexpr int NU = 8 / SW;                   // staging units per workgroup
+    constexpr int AR = 32 * SW;                  // A rows per unit
+    constexpr int ST = 64 * SW;                  // threads per unit
+    constexpr int RS = ST / 8;                   // tile rows covered by one pass of a unit's threads (8 threads x 16 B = one 32-float row)
+    constexpr int APT = AR / RS, BPT = TN / RS;  // float4 loads per thread and K step: 4 and 4
+    constexpr int UF = 2 * (AR + TN) * LDT;      // one unit's double-buffered A + B tiles (floats)
+    __shared__ __attribute__((aligned(16))) float smem[NU * UF];
+    static_assert(NU * UF >= Q * TM * TN, "the operand LDS must hold the parked accumulator tiles and their sum");
+    static_assert(NU * UF * 4 <= 160 * 1024, "LDS");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = wave / WQ, wr = wave % WQ;
-    const int gt = tid % GT;
+    const int ut = tid % ST;                     // thread index inside the staging unit
+    const int arow0 = PRIV ? wr * 32 : 0;        // tile-local row of the unit's first A row
     const int NT = a.Nout / TN;
     const int mt = blockIdx.x / NT, nt = blockIdx.x - mt * NT;
     const int m0 = mt * TM, n0 = nt * TN;
     const FvTaps& taps = a.taps[0];
     const int cpk = a.Cin / BK;
     const int nk = taps.n * cpk, per = nk / Q;   // K steps per group (nk % Q == 0: fv_conv_small_plan)
-    float* As0 = smem + q * GF;                  // [2][TM][LDT]
-    float* Bs0 = As0 + 2 * TM * LDT;             // [2][TN][LDT]
+    float* As0 = smem + (PRIV ? wave : q) * UF;  // [2][AR][LDT]
+    float* Bs0 = As0 + 2 * AR * LDT;             // [2][TN][LDT]
 
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((unsigned)a.B * a.Hin * a.Win * a.Cin * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((unsigned)a.Nout * a.Tw * a.Cin * 4u), 0x00020000);
-    const int col4 = (gt & 7) * 4, r0 = gt >> 3;
+    const int col4 = (ut & 7) * 4, r0 = ut >> 3;
     const int HWl = a.Hl * a.Wl;
     int a_pix[APT], a_oh[APT], a_ow[APT];        // image row base, input row / column of tap (0, 0) for this thread's A rows
 #pragma unroll
     for (int p = 0; p < APT; ++p) {
-        const int m = m0 + r0 + RS * p;
+        const int m = m0 + arow0 + r0 + RS * p;
         if (m < a.M) {
             const int b = m / HWl, rem = m - b * HWl, oh = rem / a.Wl, ow = rem - oh * a.Wl;
             a_pix[p] = b * a.Hin; a_oh[p] = oh * a.is; a_ow[p] = ow * a.is;
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const FvConvArgs a) 
     };
     auto stage = [&](int buf, int slot) {
 #pragma unroll
-        for (int p = 0; p < APT; ++p) *reinterpret_cast<u32x4*>(&As0[buf * TM * LDT + (r0 + RS * p) * LDT + col4]) = ra[slot][p];
+        for (int p = 0; p < APT; ++p) *reinterpret_cast<u32x4*>(&As0[buf * AR * LDT + (r0 + RS * p) * LDT + col4]) = ra[slot][p];
 #pragma unroll
         for (int p = 0; p < BPT; ++p) *reinterpret_cast<u32x4*>(&Bs0[buf * TN * LDT + (r0 + RS * p) * LDT + col4]) = rb[slot][p];
     };
@@ -100,10 +110,10 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const FvConvArgs a) 
     for (int j = 0; j < NBK; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-    const int arow = (wr * 32 + (lane & 31)) * LDT + (lane >> 5) * 4;
+    const int arow = ((PRIV ? 0 : wr * 32) + (lane & 31)) * LDT + (lane >> 5) * 4;
     const int brow = (lane & 31) * LDT + (lane >> 5) * 4;
     auto compute = [&](int cur) {                // the chunk / lane-half k order of conv_kernel
-        const float* Ac = As0 + cur * TM * LDT; const float* Bc = Bs0 + cur * TN * LDT;
+        const float* Ac = As0 + cur * AR * LDT; const float* Bc = Bs0 + cur * TN * LDT;
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
             const float4 af = *reinterpret_cast<const float4*>(&Ac[arow + kc * 8]);
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const FvConvArgs a) 
             if (s < per) {                       // uniform over the workgroup
                 stage((PF & 1) ? (s & 1) : (j & 1), j);
                 if (s + PF < per) load(j);
-                __syncthreads();
+                if constexpr (!PRIV) __syncthreads();    // private tiles: the wave's own program order is all the ordering there is to keep
                 compute((PF & 1) ? (s & 1) : (j & 1));
             }
         }
@@ -188,10 +198,11 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const FvConvArgs a) 
 }
 
 struct SmallCfg { int tm, tn, q; double step_us; };
-// K step of one group as measured (tools/bs1_shapes.py, round 5): 1.65 us with one 32 x 32 accumulator block per wave, 3.3 us with two
-// -- about twice the matrix time of the step (16 / 32 MFMAs per wave, two waves per SIMD: 0.85 / 1.7 us): a single dependent accumulator
-// chain per wave and a workgroup barrier per step; conv_kernel's K loop (two workgroups per CU, two blocks per wave) reaches 89 %.
-const SmallCfg kCfg[3] = {{64, 64, 4, 3.3}, {64, 32, 4, 1.65}, {32, 32, 8, 1.65}};
+// K step of one group as measured (tools/bs1_shapes.py, round 5; every fitting layer forced through this kernel): 1.4 us with one
+// 32 x 32 accumulator block per wave and private tiles (1.65 us when the eight waves met at a barrier every step), 2.9 us with two
+// blocks and shared tiles -- against 0.85 / 1.7 us of matrix time (16 / 32 MFMAs per wave, two waves per SIMD): one dependent
+// accumulator chain per wave and two waves per SIMD; conv_kernel's K loop (four waves per SIMD from two workgroups) reaches 89 %.
+const SmallCfg kCfg[3] = {{64, 64, 4, 2.9}, {64, 32, 4, 1.4}, {32, 32, 8, 1.4}};
 
 template <int TM, int TN, int Q>
 void launch_small(fv_ctx* ctx, const FvConvArgs& a, int grid, int per) {
@@ -207,7 +218,8 @@ void launch_small(fv_ctx* ctx, const FvConvArgs& a, int grid, int per) {
 // chain wins if it beats what the tile kernels take for such a layer: ~13 us for a 1x1 layer (8 - 16 dependent K steps on 128 x 32
 // tiles, or K slices + finish), ~28 us for a 3x3 layer (one round of K slices + the finish launch).  In Darknet-53 at batch 1 that
 // takes every 1x1 layer from 104 x 104 down (9 - 15 us instead of 12 - 19) and the stride-2 3x3 layers into 26 x 26 and 13 x 13
-// (9 steps per group); the stride-1 3x3 layers (18 steps per group: 33 - 39 us measured against 30 - 34) stay with the tile kernels.
+// (9 steps per group); the stride-1 3x3 layers (18 steps per group: 32 - 33 us measured against 30 - 33 for two launches, and slower in
+// the un-instrumented forward: 1.08 against 1.01 ms) stay with the tile kernels.
 int fv_conv_small_plan(int M, int Nout, int Cin, int ntaps) {
     if (M < 1 || Cin % BK != 0 || ntaps < 1) return 0;
     const int nk = ntaps * (Cin / BK);
