@@ -39,6 +39,11 @@ int fv_abi_version(void);
 /* stream: a hipStream_t (may be NULL = default stream).  Replaces the implicit TF session
  * that Keras creates behind FaceDetector.__init__ (fd.py:312-382). */
 int fv_create(int device, void* stream, fv_ctx** out);
+/* (The context owns a low-priority side stream for the backward overlap.  The HIP runtime multiplexes a process's streams onto
+ * GPU_MAX_HW_QUEUES hardware queues, default 4: a context created AFTER an RCCL communicator has existed in the process can find
+ * its side stream sharing a hardware queue with the compute stream, which serialises the overlap -- 30 - 40 % on a training step.
+ * Create contexts before communicators, or run the process with GPU_MAX_HW_QUEUES=8; the Python host package sets that default.
+ * DESIGN 6.) */
 void fv_destroy(fv_ctx* ctx);
 const char* fv_last_error(const fv_ctx* ctx);
 int fv_set_stream(fv_ctx* ctx, void* stream);
