@@ -283,13 +283,16 @@ def loader_bench(eng, trainer, B, S, steps):
                      'and batch k+1 staged while step k runs; loader_only_pillow = the same loader with the whole decode in Pillow on the host' % n_img)
 
 
-def test_loop_bench(device, S, n_img=256, head='single'):
+def test_loop_bench(device, S, n_img=512, head='single'):
     """FaceDetector.test() end to end (fd.py:783-883: JPEG decode -> letterbox -> predict -> decode/NMS/top-k -> back-projection
     -> csv rows) on a synthetic UCCS-format folder: images/sec at the reference's batch 1 and with the read-ahead batches of
-    hps.eval_batch_size = 16 / 32 (face_detection.FaceDetector._detect_files; 32 is the default), then at batch 32 for
+    hps.eval_batch_size = 16 / 32 / the default (face_detection.default_eval_batch: 48 at 416^2), then at the default for
     hps.loader_threads = 8 / 16 / 32 / 64.  Wall clock, host work included.  n_img: the loop is a two-deep pipeline whose first
     load and last forward overlap nothing -- with 64 images a batch of 32 is two chunks, i.e. all fill and drain (round 4's
-    three-scale 709 -> 537 img/s from batch 16 to 32 was that, not the kernels); 256 images = 8 chunks of 32."""
+    three-scale 709 -> 537 img/s from batch 16 to 32 was that, not the kernels); 512 images = 16 chunks of 32.  The loop is bound by
+    the device: `device_only` is network + decode/NMS of a batch alone (HIP events), the main thread spends
+    12-13 of its 14-16 ms per batch waiting for that (tools/test_loop_scale_probe.py: 1 971 / 2 074 / 2 255 img/s at 256 / 512 /
+    2 048 images against 2 362 device-only)."""
     import numpy as np
     from PIL import Image
     from face_vijnana_yolov3_amd import face_detection
@@ -331,24 +334,40 @@ def test_loop_bench(device, S, n_img=256, head='single'):
                     best = max(best, n_img / dt)
                 return round(best, 1)
             out = {}
-            for bs in ((1, 16, 32) if head == 'single' else (16, 32)):
+            dflt = face_detection.default_eval_batch(S)
+            for bs in ((1, 16, 32, dflt) if head == 'single' else (16, 32, dflt)):
                 conf['hps']['eval_batch_size'] = bs
                 out['batch%d' % bs] = rate()
             rows = sum(1 for _ in open(conf['output_file_path']))
+            # the device's own share of a batch of 32 (network + decode/NMS, events on the compute stream): the loop's ceiling
+            import torch
+            ceiling = {}
+            for bs in (32, dflt):
+                xs = torch.rand((bs, S, S, 3), device='cuda')
+                for _ in range(2):
+                    fd._detect_collect(fd._detect_launch(xs))
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    launched = fd._detect_launch(xs)
+                e1.record(); torch.cuda.synchronize()
+                ceiling['batch_%d' % bs] = round(bs * 5e3 / e0.elapsed_time(e1), 1)
             sweep = {}
             if head == 'single':
-                conf['hps']['eval_batch_size'] = 32
+                conf['hps']['eval_batch_size'] = dflt
                 for nt in (8, 16, 32, 64):
                     conf['hps']['loader_threads'] = nt
                     sweep[str(nt)] = rate()
         finally:
             face_detection.DEBUG = dbg
     if head != 'single':
-        return dict(unit='images/sec', eval_batch_16=out['batch16'], eval_batch_32=out['batch32'], images=n_img, csv_rows=rows,
-                    loader_threads=default_threads,
+        return dict(unit='images/sec', eval_batch_16=out['batch16'], eval_batch_32=out['batch32'], eval_batch_default=dflt,
+                    eval_batch_at_default=out['batch%d' % dflt], images=n_img, csv_rows=rows,
+                    loader_threads=default_threads, device_only=ceiling,
                     path='FaceDetector.test() with nn_arch.head = three_scale: fv_yolov3_forward + fv_yolo_decode_nms_batch (one launch pair per batch)')
-    return dict(unit='images/sec', eval_batch_1=out['batch1'], eval_batch_16=out['batch16'], eval_batch_32=out['batch32'], images=n_img, csv_rows=rows,
-                loader_threads=default_threads, eval_batch_32_by_loader_threads=sweep, host_cpus=host_cpus(),
+    return dict(unit='images/sec', eval_batch_1=out['batch1'], eval_batch_16=out['batch16'], eval_batch_32=out['batch32'],
+                eval_batch_default=dflt, eval_batch_at_default=out['batch%d' % dflt], images=n_img, csv_rows=rows,
+                loader_threads=default_threads, eval_batch_default_by_loader_threads=sweep, device_only=ceiling, host_cpus=host_cpus(),
                 path='FaceDetector.test(): %d synthetic JPEGs (768x1024 .. 720x1280), Huffman decoding on hps.loader_threads host threads (default '
                      'the usable CPUs, 4 .. 32) into reused pinned buffers one batch ahead, fv_jpeg_reconstruct_batch, fv_letterbox_batch, '
                      'fv_forward_infer, fv_decode_nms, back-projection, csv' % n_img)

@@ -13,7 +13,7 @@ ratios.csv, the model files).  Differences, all documented in DESIGN.md:
     starts num_gpus ranks itself (parallel.launch_ranks -> torch.distributed.run); a FaceDetector constructed directly in a
     process without WORLD_SIZE trains on one GPU
   * evaluate() tolerates images without ground-truth rows and a missing arial.ttf
-  * evaluate()/test() read ahead and run the network on batches of hps['eval_batch_size'] images (default 32; the
+  * evaluate()/test() read ahead and run the network on batches of hps['eval_batch_size'] images (default 48, default_eval_batch(); the
     reference's loop is batch 1, fd.py:632-883) -- same rows in the same order (text-identical for the same head output; the
     network's float32 summation order depends on the batch size, so scores may differ in the 7th digit between batch sizes)
   * train() and test() decode baseline JPEGs in two halves (jpeg.py): Huffman decoding on host threads, dequantisation / IDCT /
@@ -64,6 +64,16 @@ def default_loader_threads():
     256-thread host): 8 / 16 / 32 / 64 threads -> 1990 / 2073 / 2058 / 2021 img/s -- flat beyond the quota; the loop is bound
     by the device there (forward 0.40 ms/img = 2500 img/s, plus the JPEG reconstruction and letterbox kernels beside it)."""
     return max(4, min(32, effective_cpus()))
+
+
+def default_eval_batch(image_size):
+    """hps['eval_batch_size'] when the configuration does not set it: 48 images per forward where the first layer's output fits
+    one 2 GiB buffer descriptor (batch x image_size^2 x 32 floats <= 2^29 elements: up to 416 and beyond), else the largest
+    multiple of 8 that does (608: 40).  48, not 32: the loop is bound by the device (bench.py `test_loop`), and the 128-row tile
+    rounds of the 26^2 / 52^2 layers come out whole at multiples of 24 images (device only, network + decode/NMS at 416^2:
+    batch 24 / 32 / 40 / 48 / 64 = 2519 / 2360 / 2510 / 2610 / 2565 img/s, tools/eval_batch_probe.py)."""
+    fit = (1 << 29) // (32 * int(image_size) * int(image_size))
+    return 48 if fit >= 48 else max(1, fit // 8 * 8 if fit >= 8 else fit)
 
 
 def map_all(pool, fn, items):
@@ -327,7 +337,7 @@ class FaceDetector(object):
         -- batch 1 is the slowest operating point of the network (1.3 ms/img against 0.4 at batch 16+).  Two deep: the loader
         thread fills a reused pinned buffer (PinnedRing) with batch k+1 while batch k is in the device queue and the host turns
         batch k-1's result into BoundBoxes and rows."""
-        bs = max(1, int(self.hps.get('eval_batch_size', 32)))
+        bs = max(1, int(self.hps.get('eval_batch_size', default_eval_batch(self.image_size))))
         chunks = [files[i:i + bs] for i in range(0, len(files), bs)]
         if not chunks:
             return

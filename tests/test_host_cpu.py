@@ -211,3 +211,16 @@ def test_default_loader_threads_respects_affinity_and_quota():
     assert 1 <= n <= (os.cpu_count() or n)
     assert 4 <= fdm.default_loader_threads() <= 32
     assert fdm.default_loader_threads() == max(4, min(32, n))
+
+
+def test_default_eval_batch_fits_one_buffer_descriptor():
+    """evaluate()/test() batch when hps.eval_batch_size is absent: 48 where the first layer's output (batch x S^2 x 32 floats) stays
+    within the 2^29 elements a 2 GiB buffer descriptor addresses (fv_forward_infer refuses more), the largest multiple of 8 below
+    that otherwise."""
+    from face_vijnana_yolov3_amd.face_detection import default_eval_batch
+    assert default_eval_batch(416) == 48 and default_eval_batch(320) == 48
+    assert default_eval_batch(608) == 40
+    for s in range(96, 4097, 32):
+        b = default_eval_batch(s)
+        assert b >= 1 and (b == 1 or b * s * s * 32 <= 1 << 29)
+        assert b == 48 or (b + 8) * s * s * 32 > 1 << 29 or b < 8
