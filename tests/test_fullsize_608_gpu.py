@@ -84,3 +84,25 @@ def test_608_gradient_matches_directional_derivative(eng, batch):
     eng.set_params(p0, s0)
     eng.grads = eng.m = eng.v = None
     assert min(abs(r - 1.0) for r in ratios) < 0.05, ratios
+
+
+def test_608_default_eval_batch_is_the_largest_the_forward_accepts(eng, batch):
+    """evaluate()/test() read ahead default_eval_batch(608) = 40 images: the largest multiple of 8 whose first-layer output (batch x 608^2 x
+    32 floats) one 2 GiB buffer descriptor addresses.  That batch runs and agrees per image with the batch-16 forward; 48 images -- the
+    default at 416 -- are refused with an error that says why, the context stays usable."""
+    from face_vijnana_yolov3_amd._lib import FvError
+    from face_vijnana_yolov3_amd.face_detection import default_eval_batch
+    x, _ = batch
+    nb = default_eval_batch(S)
+    assert nb == 40
+    y16 = eng.predict_device(x).clone()
+    xb = torch.cat([x, x, x[:nb - 2 * B]])
+    yb = eng.predict_device(xb).clone()
+    torch.cuda.synchronize()
+    assert tuple(yb.shape) == (nb, 19, 19, 6)
+    scale = y16.abs().max().item()
+    assert (yb[:B] - y16).abs().max().item() <= 2e-5 * scale and (yb[B:2 * B] - y16).abs().max().item() <= 2e-5 * scale
+    del yb
+    with pytest.raises(FvError, match='2 GiB'):
+        eng.predict_device(torch.cat([x, x, x]))
+    assert torch.equal(eng.predict_device(x), y16)
