@@ -95,12 +95,23 @@ class Engine(object):
             x = x.to(device=self.dev, dtype=torch.float32)
         return x.contiguous()
 
+    @staticmethod
+    def max_infer_batch(image_size):
+        """Largest batch one fv_forward_infer call takes at this image size: the kernels address a tensor through one buffer descriptor
+        (2 GiB, 2^29 floats) and the largest activation is the first layer's batch x S x S x 32 output."""
+        return (1 << 29) // (32 * int(image_size) * int(image_size))
+
     # ------------------------------------------------------------------ predict (fd.py:899)
     def predict_device(self, x):
         """x: (B,S,S,3) float in [0,1] -> (B,S/32,S/32,6) float32 CUDA tensor (stream-ordered)."""
         x = self._as_input(x)
         B, S = x.shape[0], x.shape[1]
         assert x.dim() == 4 and x.shape[2] == S and x.shape[3] == 3
+        cap = self.max_infer_batch(S)
+        if B > cap >= 1:
+            # inference is per image (moving statistics): a batch beyond what fv_forward_infer addresses runs in parts
+            step = cap // 8 * 8 if cap >= 8 else cap
+            return torch.cat([self.predict_device(x[i:i + step]) for i in range(0, B, step)])
         ws = self._workspace(B, S, False)
         y = torch.empty((B, S // 32, S // 32, HEAD_C), dtype=torch.float32, device=self.dev)
         rc = lib().fv_forward_infer(self.ctx.handle, ptr(self.params), ptr(self.state), ptr(x), B, S, ptr(ws), ws.numel(), ptr(y))
@@ -116,6 +127,11 @@ class Engine(object):
         x = self._as_input(x)
         B, S = x.shape[0], x.shape[1]
         assert x.dim() == 4 and x.shape[2] == S and x.shape[3] == 3
+        cap = self.max_infer_batch(S)
+        if B > cap >= 1:
+            step = cap // 8 * 8 if cap >= 8 else cap
+            parts = [self.predict_base_device(x[i:i + step], with_head) for i in range(0, B, step)]
+            return (torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])) if with_head else torch.cat(parts)
         ws = self._workspace(B, S, False)
         feat = torch.empty((B, S // 32, S // 32, self.layers[-1]['cin']), dtype=torch.float32, device=self.dev)
         y = torch.empty((B, S // 32, S // 32, HEAD_C), dtype=torch.float32, device=self.dev) if with_head else None

@@ -72,7 +72,8 @@ def default_eval_batch(image_size):
     multiple of 8 that does (608: 40).  48, not 32: the loop is bound by the device (bench.py `test_loop`), and the 128-row tile
     rounds of the 26^2 / 52^2 layers come out whole at multiples of 24 images (device only, network + decode/NMS at 416^2:
     batch 24 / 32 / 40 / 48 / 64 = 2519 / 2360 / 2510 / 2610 / 2565 img/s, tools/eval_batch_probe.py)."""
-    fit = (1 << 29) // (32 * int(image_size) * int(image_size))
+    from .engine import Engine
+    fit = Engine.max_infer_batch(image_size)
     return 48 if fit >= 48 else max(1, fit // 8 * 8 if fit >= 8 else fit)
 
 

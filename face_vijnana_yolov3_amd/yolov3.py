@@ -89,6 +89,11 @@ class Yolov3(object):
     def predict_device(self, x):
         x = torch.as_tensor(x).to(device=self.dev, dtype=torch.float32).contiguous()
         B, S = x.shape[0], x.shape[1]
+        cap = (1 << 29) // (32 * S * S)              # one buffer descriptor per tensor: see Engine.max_infer_batch
+        if B > cap >= 1:
+            step = cap // 8 * 8 if cap >= 8 else cap
+            parts = [self.predict_device(x[i:i + step]) for i in range(0, B, step)]
+            return [torch.cat([p[k] for p in parts]) for k in range(3)]
         key = (B, S)
         if key not in self._ws:
             n = int(lib().fv_yolov3_workspace_bytes(B, S, self.out_channels))

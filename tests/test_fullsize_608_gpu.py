@@ -89,8 +89,9 @@ def test_608_gradient_matches_directional_derivative(eng, batch):
 def test_608_default_eval_batch_is_the_largest_the_forward_accepts(eng, batch):
     """evaluate()/test() read ahead default_eval_batch(608) = 40 images: the largest multiple of 8 whose first-layer output (batch x 608^2 x
     32 floats) one 2 GiB buffer descriptor addresses.  That batch runs and agrees per image with the batch-16 forward; 48 images -- the
-    default at 416 -- are refused with an error that says why, the context stays usable."""
-    from face_vijnana_yolov3_amd._lib import FvError
+    default at 416 -- are refused by the C entry point with an error that says why (the context stays usable), and Engine.predict_device
+    runs them in parts (inference is per image)."""
+    from face_vijnana_yolov3_amd._lib import FvError, lib, ptr
     from face_vijnana_yolov3_amd.face_detection import default_eval_batch
     x, _ = batch
     nb = default_eval_batch(S)
@@ -103,6 +104,16 @@ def test_608_default_eval_batch_is_the_largest_the_forward_accepts(eng, batch):
     scale = y16.abs().max().item()
     assert (yb[:B] - y16).abs().max().item() <= 2e-5 * scale and (yb[B:2 * B] - y16).abs().max().item() <= 2e-5 * scale
     del yb
+    x48 = torch.cat([x, x, x])
+    assert eng.max_infer_batch(S) == 45
+    ws = eng._workspace(48, S, False)
+    y48 = torch.empty((48, 19, 19, 6), dtype=torch.float32, device='cuda')
+    rc = lib().fv_forward_infer(eng.ctx.handle, ptr(eng.params), ptr(eng.state), ptr(x48), 48, S, ptr(ws), ws.numel(), ptr(y48))
     with pytest.raises(FvError, match='2 GiB'):
-        eng.predict_device(torch.cat([x, x, x]))
+        eng.ctx.check(rc, 'fv_forward_infer')
+    y48 = eng.predict_device(x48)                # 40 + 8
+    torch.cuda.synchronize()
+    assert tuple(y48.shape) == (48, 19, 19, 6)
+    for k in range(3):
+        assert (y48[k * B:(k + 1) * B] - y16).abs().max().item() <= 2e-5 * scale
     assert torch.equal(eng.predict_device(x), y16)
