@@ -171,7 +171,7 @@ size_t fv_workspace_bytes(int batch, int image_size, int training);
  * into the conv epilogue), x [batch][S][S][3] float32 NHWC in [0,1], y [batch][S/32][S/32][6].
  * Every tensor is addressed through one 2 GiB buffer descriptor: batch * S * S * 32 (the first layer's output) must not exceed
  * 2^29 floats -- 96 images at 416, 45 at 608; beyond that the call returns FV_ERR_INVALID ("... exceeds 2^29 elements (2 GiB buffer
- * descriptor) ...") before anything is launched, and the caller splits the batch (inference is per image; the Python host does). The
+ * descriptor) ...") at the first convolution, before any of them is launched, and the caller splits the batch (inference is per image; the Python host does). The
  * same bound holds for fv_forward_base, fv_train_step and the fv_yolov3_* entry points. */
 int fv_forward_infer(fv_ctx* ctx, const float* params, const float* bn_state, const float* x, int batch,
                      int image_size, void* workspace, size_t workspace_bytes, float* y);
