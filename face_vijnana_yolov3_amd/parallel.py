@@ -102,6 +102,8 @@ class DataParallelTrainer(object):
         self.auto_report = None
         self._auto_k = None
         self._auto_ms = []
+        self._auto_skip = False
+        self.auto_abandoned = {}
         if self.comm_mode == 'auto':
             self.comm_mode = 'wg'
             # resolved in train_on_batch (needs a process group to be worth measuring); a trainer without the bucket path has
@@ -174,6 +176,7 @@ class DataParallelTrainer(object):
     AUTO_WARM, AUTO_STEPS = 3, 8
     AUTO_MODES = ('wg', 'main', 'pg')
     AUTO_MARGIN = 0.01       # 'wg' is kept unless another mode is more than this fraction faster
+    AUTO_ABANDON = 3.0       # a mode whose first step takes more than this many 'wg' steps is dropped without being timed
 
     def _auto_tick(self):
         """comm_mode 'auto': called at the top of every step until decided.  AUTO_WARM steps warm up in 'wg'; then every mode
@@ -192,9 +195,12 @@ class DataParallelTrainer(object):
         per = S + 1                               # steps per mode: one warm-up + S timed
         if k >= W:
             j, r = divmod(k - W, per)
-            if r == 0 and j > 0:                  # mode j-1 has run its S timed steps
+            if r == 0 and j > 0:                  # mode j-1 has run its S timed steps (or was dropped after its first)
                 torch.cuda.synchronize(self.eng.dev)
-                self._auto_ms.append((time.perf_counter() - self._auto_t0) / S * 1e3)
+                if self._auto_skip:
+                    self._auto_skip = False
+                else:
+                    self._auto_ms.append((time.perf_counter() - self._auto_t0) / S * 1e3)
             if r == 0 and j == len(self.AUTO_MODES):
                 t = torch.tensor(self._auto_ms, dtype=torch.float64, device=self.eng.dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -203,13 +209,30 @@ class DataParallelTrainer(object):
                 self.comm_mode = best if ms[best] < ms['wg'] * (1.0 - self.AUTO_MARGIN) else 'wg'
                 self.auto_report = dict(ms_per_step={m: round(v, 3) for m, v in ms.items()}, chosen=self.comm_mode, steps_each=S,
                                         rule="'wg' unless another mode is more than %g %% faster" % (100 * self.AUTO_MARGIN))
+                if self.auto_abandoned:
+                    self.auto_report['dropped_after_first_step_ms'] = dict(self.auto_abandoned)
                 self._auto_k = None
                 return
             if r == 0:
                 self.comm_mode = self.AUTO_MODES[j]
+                torch.cuda.synchronize(self.eng.dev)
+                self._auto_tw = time.perf_counter()
             elif r == 1:
                 torch.cuda.synchronize(self.eng.dev)
                 self._auto_t0 = time.perf_counter()
+                if j > 0:
+                    # A mode whose FIRST step is several times slower than a 'wg' step is not a candidate: drop it after that one step
+                    # instead of timing eight more (two ranks rehearsing on one GPU with GPU_MAX_HW_QUEUES=8: 'pg' took 17 s per
+                    # step -- more streams than hardware queues left for two processes).  Decided on max-reduced numbers: alike everywhere.
+                    t = torch.tensor([(self._auto_t0 - self._auto_tw) * 1e3, self._auto_ms[0]], dtype=torch.float64, device=self.eng.dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    warm_ms, wg_ms = (float(v) for v in t.cpu())
+                    if warm_ms > self.AUTO_ABANDON * wg_ms:
+                        self._auto_ms.append(warm_ms)
+                        self.auto_abandoned[self.AUTO_MODES[j]] = round(warm_ms, 3)
+                        k = W + (j + 1) * per - 1              # the next tick is the next mode's r == 0 (or the decision)
+                        self.comm_mode = 'wg'                  # this step itself runs in the trusted mode
+                        self._auto_skip = True
         self._auto_k = k + 1
 
     @property
